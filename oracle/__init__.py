@@ -1,0 +1,37 @@
+"""CPU oracle for the onset-fingerprinting hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package; the product (``onset_fingerprinting_amd``) never
+does.  It restates the reference's algorithm on the CPU (plain C for the
+detector, numpy for framing / STFT / mel / classifier forward) and is pinned
+against golden vectors captured from the reference itself
+(``tests/golden/make_golden.py``).  Parity status per function is in each
+docstring; reference paths are under ``/root/reference/onset_fingerprinting/``.
+"""
+from .detector import (  # noqa: F401
+    OracleDetector,
+    ar_envelope,
+    backtrack_onsets,
+    butter_hp_f32,
+    detect_onsets_amplitude,
+    exp10f,
+    host_math_probe,
+    lfilter4,
+    lib,
+    log10f,
+    minmax_envelope,
+    rect_db,
+    rel_linear,
+)
+from .spectral import (  # noqa: F401
+    cspec_to_mfcc,
+    dense_power_frames,
+    frame_extract,
+    hann_periodic,
+    mel_filterbank,
+    power_to_db,
+    stft,
+    stft_frame,
+    window_contribution_weights,
+)
+from .classifier import cnn_forward, fcnn_forward  # noqa: F401

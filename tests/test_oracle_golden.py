@@ -1,0 +1,223 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the
+reference (tests/golden/make_golden.py).  CPU only."""
+import ast
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.conftest import load_golden
+from onset_fingerprinting_amd import synth
+from tests.golden.make_golden_cfg import G3_CONFIGS
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def test_g1_ar_envelope_bit_exact():
+    g = load_golden("g1_ar_envelope")
+    x = g["x"]
+    B, C = 64, x.shape[1]
+    for k, (a, r) in enumerate(g["pairs"]):
+        y = np.full((B, C), -70.0, np.float32)
+        outs = []
+        for i in range(0, len(x), B):
+            oracle.ar_envelope(np.ascontiguousarray(x[i:i + B]), y, np.float32(1 / a), np.float32(1 / r))
+            outs.append(y.copy())
+        got = np.concatenate(outs)
+        assert np.array_equal(got.view(np.uint32), g[f"y{k}"].view(np.uint32)), (a, r)
+
+
+def test_g2_minmax_bit_exact():
+    g = load_golden("g2_minmax")
+    x, B = g["x"], int(g["B"])
+    C = x.shape[1]
+    for (mn0, mx0, am, aM, mm, kmin, kmax) in ((0, 10, 1e-4, 1e-5, 2.0, "mins", "maxs"),
+                                               (1, 3, 1e-2, 3e-3, 0.0, "mins2", "maxs2")):
+        mn = np.full(C, mn0, np.float32)
+        mx = np.full(C, mx0, np.float32)
+        for i in range(0, len(x), B):
+            oracle.minmax_envelope(np.ascontiguousarray(x[i:i + B]), mn, mx, np.float32(am), np.float32(aM), np.float32(mm))
+            assert np.array_equal(mn.view(np.uint32), g[kmin][i // B].view(np.uint32))
+            assert np.array_equal(mx.view(np.uint32), g[kmax][i // B].view(np.uint32))
+
+
+def test_g9_backtrack_exact():
+    g = load_golden("g9_backtrack")
+    for k in range(3):
+        d = g["deltas0"].copy()
+        oracle.backtrack_onsets(g["buf"], g["channels"], d, g[f"alpha_{k}"], g[f"tol_{k}"], int(g["B"]))
+        assert np.array_equal(d, g[f"deltas_{k}"])
+
+
+def test_g11_lfilter_bit_exact():
+    g = load_golden("g11_lfilter")
+    x = g["x"]
+    for k in range(3):
+        cut, sr = g[f"cfg{k}"]
+        b, a = oracle.butter_hp_f32(cut, 4, sr)
+        assert np.array_equal(b, g[f"b{k}"]) and np.array_equal(a, g[f"a{k}"])
+        zi = np.zeros((4, 3), np.float32)
+        ys = [oracle.lfilter4(x[i:i + 500], b, a, zi) for i in range(0, 3000, 500)]
+        y = np.concatenate(ys)
+        assert np.array_equal(y.view(np.uint32), g[f"y{k}"].view(np.uint32))
+        assert np.array_equal(zi.view(np.uint32), g[f"zi{k}"].view(np.uint32))
+
+
+def host_math_matches():
+    """True when this host's numpy float32 log10/power reproduce the machine the
+    goldens were captured on (then the restatement must match them bit-for-bit)."""
+    g = load_golden("g0_hostmath")
+    _, la, _, pv = oracle.host_math_probe()
+    return np.array_equal(la.view(np.uint32), g["log10"].view(np.uint32)) and \
+        np.array_equal(pv.view(np.uint32), g["pow10"].view(np.uint32))
+
+
+def chaotic(cfg):
+    """attack < 1 sample => follower coefficient > 1: rounding differences are
+    amplified (|1 - 1/attack| > 1 per step), so the relative envelope depends on
+    the last ulp of log10 -- on the reference too (host-CPU dependent)."""
+    return cfg.get("fast_ar", (3.0, 383.0))[0] < 1.0
+
+
+def _run_blocks(od, x, B):
+    recs, rels = [], []
+    for i in range(0, len(x) - B + 1, B):
+        c, d, r = od(x[i:i + B])
+        rels.append(r)
+        recs += [(i // B, int(cc), int(dd)) for cc, dd in zip(c, d)]
+    return np.array(recs, np.int64).reshape(-1, 3), np.concatenate(rels)
+
+
+@pytest.mark.parametrize("k", range(len(G3_CONFIGS)))
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g3_detector_blocks(k, tag):
+    g = load_golden("g3_detector_blocks")
+    sr = int(g["sr"])
+    x = g["x"] if tag == "a" else g["x2"]
+    cfg = dict(G3_CONFIGS[k])
+    assert repr(cfg) == str(g[f"cfg_{k}"])
+    B = cfg.pop("block_size")
+    C = x.shape[1]
+    gs = g[f"state_{k}{tag}"]
+    ref_rel = g[f"rel_{k}{tag}"]
+    # (1) restatement with the host numpy's log10/power: EVERYTHING bit-exact
+    if host_math_matches():
+        od = oracle.OracleDetector(C, B, sr=sr, host_math=True, **cfg)
+        if k % 2 == 1:
+            od.init_minmax_tracker(x[: int(0.05 * sr)])
+        recs, rel = _run_blocks(od, x, B)
+        assert np.array_equal(recs, g[f"rec_{k}{tag}"])
+        assert np.array_equal(rel[::5].view(np.uint32), ref_rel.view(np.uint32))
+        assert np.array_equal(rel.astype(np.float64).sum(0), g[f"relsum_{k}{tag}"])
+        st = od.state()
+        got = np.concatenate([st["state"].astype(np.float64), st["prev"], st["deb"].astype(np.float64),
+                              st["mn"].astype(np.float64), st["mx"].astype(np.float64)])
+        assert np.array_equal(got, gs)
+    # (2) the canon (fp64-evaluated log10/exp10): onset records exact, floats close
+    od = oracle.OracleDetector(C, B, sr=sr, **cfg)
+    if k % 2 == 1:
+        od.init_minmax_tracker(x[: int(0.05 * sr)])
+    recs, rel = _run_blocks(od, x, B)
+    assert np.array_equal(recs, g[f"rec_{k}{tag}"]), (recs, g[f"rec_{k}{tag}"])
+    st = od.state()
+    assert np.array_equal(st["state"].astype(np.float64), gs[:C])
+    assert np.array_equal(st["deb"].astype(np.float64), gs[2 * C:3 * C])
+    if not chaotic(cfg):
+        np.testing.assert_allclose(rel[::5], ref_rel, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(rel.astype(np.float64).sum(0), g[f"relsum_{k}{tag}"], rtol=1e-5)
+        np.testing.assert_allclose(st["prev"], gs[C:2 * C], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(st["mn"], gs[3 * C:4 * C], rtol=2e-5)
+        np.testing.assert_allclose(st["mx"], gs[4 * C:5 * C], rtol=2e-5)
+
+
+@pytest.mark.parametrize("host_math", [True, False])
+def test_g4_end_to_end_indices_exact(host_math):
+    if host_math and not host_math_matches():
+        pytest.skip("host numpy float32 log10/power differ from the capture machine")
+    g = load_golden("g4_end_to_end")
+    sr = 48000
+    hm = dict(host_math=host_math)
+
+    def close(a, b, **kw):
+        if host_math:
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        else:
+            np.testing.assert_allclose(a, b, **kw)
+
+    x1 = synth.c1_sine_clicks(10.0, sr, seed=0)
+    assert x1.astype(np.float64).sum() == g["c1_xsum"], "synthetic generator drifted"
+    for B in (128, 256):
+        c, o, rel = oracle.detect_onsets_amplitude(x1, block_size=B, sr=sr, **hm)
+        assert np.array_equal(np.array(c), g[f"c1_B{B}_ch"])
+        assert np.array_equal(np.array(o), g[f"c1_B{B}_on"])
+        close(rel[::97], g[f"c1_B{B}_rel"], rtol=2e-5, atol=1e-7)
+        close(rel.astype(np.float64).sum(0), g[f"c1_B{B}_relsum"], rtol=1e-5)
+    x2 = synth.c2_drums(10.0, 8, sr, seed=1)
+    assert x2.astype(np.float64).sum() == g["c2_xsum"]
+    c, o, rel = oracle.detect_onsets_amplitude(x2, block_size=256, sr=sr, **hm)
+    assert np.array_equal(np.array(c), g["c2_ch"]) and np.array_equal(np.array(o), g["c2_on"])
+    assert len(c) > 100
+    close(rel[::997], g["c2_rel"], rtol=2e-5, atol=1e-7)
+    c, o, rel = oracle.detect_onsets_amplitude(
+        x2[:, :3].copy(), block_size=128, hipass_freq=0, fast_ar=(0.3, 800.0),
+        slow_ar=(8000.0, 8000.0), on_threshold=0.45, off_threshold=0.45, cooldown=9600, sr=sr, **hm)
+    if host_math:
+        assert np.array_equal(np.array(c), g["rt_ch"]) and np.array_equal(np.array(o), g["rt_on"])
+    else:
+        # attack 0.3 => coefficient 3.33: rounding-chaotic (see chaotic()); the
+        # noise-triggered onsets of the first second depend on the last ulp of
+        # log10 on the reference too.  The hit-driven onsets must still agree.
+        c, o = np.array(c), np.array(o)
+        keep, gkeep = o >= sr, g["rt_on"] >= sr
+        assert np.array_equal(c[keep], g["rt_ch"][gkeep]) and np.array_equal(o[keep], g["rt_on"][gkeep])
+    x4 = synth.c4_clip(7, 4.0, 4, sr)
+    assert x4.astype(np.float64).sum() == g["c4_xsum"]
+    c, o, rel = oracle.detect_onsets_amplitude(x4, block_size=256, sr=sr, **hm)
+    assert np.array_equal(np.array(c), g["c4_ch"]) and np.array_equal(np.array(o), g["c4_on"])
+
+
+def test_g6_stft():
+    g = load_golden("g6_stft")
+    for k, case in enumerate(g["cases"]):
+        name, method, L, hop, nfft, hep, onset = ast.literal_eval(str(case))
+        S = oracle.stft(g[name], onset, L, hop, nfft, bool(hep), method)
+        ref = g[f"S{k}"]
+        assert S.shape == ref.shape and S.dtype == ref.dtype
+        np.testing.assert_allclose(S, ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+    w = oracle.hann_periodic(256)
+    np.testing.assert_allclose(oracle.stft_frame(g["frame_x"], 256, w), g["frame_S"], rtol=1e-12, atol=1e-12)
+
+
+def test_g7_frames_exact():
+    g = load_golden("g7_frames")
+    a, o = g["audio"], g["onsets"]
+    assert np.array_equal(oracle.frame_extract(a, o, 256, 16), g["f1"])
+    assert np.array_equal(oracle.frame_extract(a, o, 256, 16, use_min_onset=False), g["f2"])
+    assert np.array_equal(oracle.frame_extract(a, o, 128, 32, add_pre_samples=True), g["f3"])
+    assert np.array_equal(oracle.frame_extract(a[:, 0].copy(), o[:, 0], 64, 8), g["f1d"])
+
+
+def test_g10_window_contribution_weights():
+    g = load_golden("g10_wcw")
+    np.testing.assert_allclose(oracle.window_contribution_weights(oracle.hann_periodic(256), 64), g["w256_64"], rtol=1e-12)
+    w = oracle.hann_periodic(1024)
+    np.testing.assert_allclose(oracle.window_contribution_weights(w, 256), g["w1024_256"], rtol=1e-12)
+    np.testing.assert_allclose(oracle.window_contribution_weights(w, 256, True), g["w1024_256_hep"], rtol=1e-12)
+
+
+def test_g8_models():
+    g = load_golden("g8_models")
+    for name in ("fc_a", "fc_b", "fc_c"):
+        sd = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/network")}
+        y = oracle.fcnn_forward(sd, g[f"{name}/x"], activation=str(g[f"{name}/act"]))
+        np.testing.assert_allclose(y, g[f"{name}/y"], rtol=1e-4, atol=1e-5)
+    for name, kw in (("cnn_a", {}), ("cnn_b", dict(padding=2))):
+        sd = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/") and k.split("/")[1] not in ("x", "y")}
+        y = oracle.cnn_forward(sd, g[f"{name}/x"], **kw)
+        np.testing.assert_allclose(y, g[f"{name}/y"], rtol=1e-4, atol=1e-5)
