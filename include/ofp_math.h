@@ -26,8 +26,9 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define OFP_HD __host__ __device__ __forceinline__
-#define OFP_D __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#define OFP_HD __host__ __device__ inline __attribute__((always_inline))
+#define OFP_D __device__ inline __attribute__((always_inline))
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OFP_TABLE_QUAL static __device__ const
 #else

@@ -1,0 +1,214 @@
+/*
+ * onsetfp.h -- C ABI of libonsetfp.so, the MI355X (gfx950) implementation of the
+ * onset-fingerprinting hot path:
+ *
+ *   envelope follower / amplitude onset detector  ->  framing + Hann + rFFT
+ *   power spectrum  ->  mel fingerprint  ->  small classifier forward.
+ *
+ * Plain pointers and sizes only; no torch or C++ types.  All `d_` pointers are
+ * DEVICE pointers (HBM); `stream` is a hipStream_t passed as void* (NULL = the
+ * null stream).  Every entry point except the three legacy symbols returns an
+ * int status (OFP_OK == 0) and records a message retrievable with
+ * ofp_last_error().  The library never allocates inside a launch function:
+ * work space is provided by the caller (size from the *_workspace_bytes
+ * query), so every launch function can be captured into a hipGraph.
+ *
+ * Reference interfaces replaced (paths under the upstream repo's
+ * onset_fingerprinting/ directory):
+ *   envelope_follower.c:6,27,59     the ctypes boundary of detection.py:517-578
+ *   detection.py:595-888            AmplitudeOnsetDetector (__call__, warm-up)
+ *   detection.py:19-86              detect_onsets_amplitude driver loop
+ *   data.py:55-120                  FrameExtractor gather
+ *   data.py:581-654                 stft_frame / stft
+ *   data.py:657-680                 cspec_to_mfcc (mel + dB + DCT)
+ *   calibration.py:463-560          FCNN forward
+ *   model.py:52-120                 CNN forward
+ */
+#ifndef ONSETFP_H
+#define ONSETFP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFP_OK 0
+#define OFP_ERR_INVALID 1   /* bad argument (shape, NULL, unsupported option) */
+#define OFP_ERR_HIP 2       /* a HIP runtime call or kernel launch failed */
+#define OFP_ERR_NODEVICE 3  /* no usable GPU */
+#define OFP_ERR_WORKSPACE 4 /* caller-provided work space too small */
+#define OFP_ERR_NOCONVERGE 5 /* speculative time-parallel pass did not converge */
+
+#define OFP_ABI_VERSION 1
+
+/* ---- status ---------------------------------------------------------------- */
+int ofp_abi_version(void);
+const char* ofp_last_error(void);
+/* number of visible GPUs (>= 0) or a negative OFP_ERR_* */
+int ofp_device_count(void);
+/* writes the gcnArchName of `device` into buf; fails unless it is gfx950 */
+int ofp_device_check(int device, char* buf, int buflen);
+
+/* ---- legacy symbols: drop-in for envelope_follower.so ---------------------------
+ * Identical names, signatures and HOST-pointer semantics as envelope_follower.c:6,
+ * :27 and :59, so that the reference's detection.py:517-578 can CDLL this library
+ * unchanged.  Each call stages its arrays to the GPU, runs one kernel and copies
+ * the in/out arrays back; they return void and report failures only through
+ * ofp_last_error() (the reference ABI has no status).  */
+void ar_envelope(float* x, float* y, float attack, float release, int size, int num_samples);
+void minmax_envelope(float* x, float* min_val, float* max_val, float alpha_min, float alpha_max,
+                     float minmin, int n_samples, int n_channels);
+void backtrack_onsets(float* buffer, long* channels, long* deltas, float alpha, float tol,
+                      long buffer_length, long n_onsets, long n_channels, long block_size);
+
+/* ---- amplitude onset detector (detection.py:595-888) ----------------------------- */
+typedef struct ofp_detector_params {
+    int32_t n_channels;   /* C: signals per detector instance (detection.py:633) */
+    int32_t block_size;   /* B (detection.py:634) */
+    float floor_db;       /* floor (detection.py:635) */
+    int32_t hp_enabled;   /* hipass_freq != 0 (detection.py:692-696) */
+    float hp_b[5];        /* np.float32(butter(4, f, "high", fs=sr)) (detection.py:492-496) */
+    float hp_a[5];
+    float fast_attack;    /* np.float32(1/attack): the COEFFICIENT (detection.py:514-515) */
+    float fast_release;
+    float slow_attack;
+    float slow_release;
+    float alpha_min;      /* 1e-4 (detection.py:705) */
+    float alpha_max;      /* 1e-5 */
+    float minmin;         /* 2 */
+    float min0;           /* tracker start: 0 (detection.py:704) */
+    float max0;           /* 10 */
+    int32_t manual;       /* scalar on_threshold > 1 (detection.py:687) */
+    int64_t cooldown;     /* samples (detection.py:640) */
+    int32_t backtrack;    /* detection.py:641 */
+    int64_t backtrack_buffer_size;
+    float backtrack_alpha; /* np.float32(2/(smooth+1)) (detection.py:722) */
+    float backtrack_tol;   /* np.float32((1-alpha)**buffer_size) (detection.py:723-725) */
+} ofp_detector_params;
+
+/* one detected onset: 16 bytes, also the record all-gathered across ranks */
+typedef struct ofp_onset {
+    int32_t clip;     /* clip (detector instance) index within the call */
+    int32_t channel;  /* channel index in [0, C) */
+    int64_t sample;   /* block_start + delta, relative to the clip's first sample */
+} ofp_onset;
+
+/* tuning of the speculative time-parallel passes; zero-initialise for defaults */
+typedef struct ofp_detect_tuning {
+    int64_t hp_chunk, hp_warm;   /* samples per chunk / speculative warm-up, IIR stage */
+    int64_t ar_chunk, ar_warm;   /* follower stage */
+    int64_t mm_chunk, mm_warm;   /* min/max tracker stage */
+    int32_t max_passes;          /* repair passes before giving up (0: no limit) */
+} ofp_detect_tuning;
+
+typedef struct ofp_detector ofp_detector; /* opaque */
+
+/* on_threshold / off_threshold: C doubles each (the reference's scalar broadcast,
+ * or per-channel values as set by AmplitudeOnsetDetector.init, detection.py:866-867) */
+int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold,
+                        const double* off_threshold, ofp_detector** out);
+int ofp_detector_destroy(ofp_detector* det);
+int ofp_detector_set_tuning(ofp_detector* det, const ofp_detect_tuning* t);
+
+/* Work space (bytes) ofp_detect_offline needs for n_clips clips of n_samples. */
+int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int64_t n_samples,
+                                   int64_t warm_samples);
+
+/* detect_onsets_amplitude (detection.py:19-86) for a batch of independent clips.
+ *   d_x        [n_clips][n_samples][C] float32, interleaved as the reference expects
+ *   warm       number of leading samples double-processed by init_minmax_tracker
+ *              (detection.py:70: int(0.5*sr)); clipped to n_samples; 0 = no warm-up
+ *   d_rel      [n_clips][floor(n_samples/B)*B][C] float32 relative envelope, or NULL
+ *   d_records  [n_clips][cap_per_clip] onset records, ordered as the reference orders
+ *              them (block, then channel)
+ *   d_counts   [n_clips] int64 number of onsets per clip (may exceed cap_per_clip:
+ *              only cap_per_clip are stored)
+ *   d_ws       work space of at least ofp_detect_workspace_bytes()
+ * Synchronises `stream` internally (the speculative passes are verified on the
+ * host); on return all outputs are complete.  h_info (optional, host) receives
+ * {hp passes, follower passes, tracker passes, repaired chunks}. */
+int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                       int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
+                       int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info,
+                       void* stream);
+
+/* Streaming form: AmplitudeOnsetDetector.__call__ (detection.py:727-798) on
+ * n_blocks consecutive blocks with the detector state carried in d_state
+ * (ofp_stream_state_bytes() bytes, initialised by ofp_stream_state_init).
+ * One launch, no host synchronisation: capturable into a hipGraph.
+ *   d_x [n_blocks*B][C]; d_rel same shape or NULL; d_records [cap]; d_count [1]
+ *   (int64, ACCUMULATED: zero it to start a new list); record.sample is relative to
+ *   sample_base + the first sample of this call.
+ *   warmup != 0: run init_minmax_tracker (detection.py:827-840) over the n_rows
+ *   rows of d_x instead (n_blocks is then ignored; rows beyond the last full block
+ *   pass through the high-pass filter only). */
+int64_t ofp_stream_state_bytes(const ofp_detector* det);
+int ofp_stream_state_init(ofp_detector* det, void* d_state, void* stream);
+int ofp_stream_process(ofp_detector* det, void* d_state, const float* d_x, int64_t n_blocks,
+                       int64_t n_rows, int32_t warmup, int64_t sample_base, float* d_rel,
+                       ofp_onset* d_records, int64_t cap, int64_t* d_count, void* stream);
+
+/* ---- framing + STFT (data.py:55-120, 581-654) ------------------------------------ */
+/* Dense power spectra, the metric's frame definition (one frame per hop):
+ *   d_x [n_clips][n_samples][C] interleaved;  frame h of channel c covers samples
+ *   [h*hop, h*hop + n_fft);  H = 1 + (n_samples - n_fft)/hop.
+ *   d_power [n_clips][C][H][n_fft/2+1] float32 = |rfft(hann_periodic(n_fft) * frame)|^2
+ *   n_fft in {256, 512, 1024, 2048, 4096}.  d_power may be NULL when only the mel
+ *   output below is wanted. */
+int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels,
+                   int32_t n_fft, int32_t hop, float* d_power, void* stream);
+
+/* Gathered complex STFT frames (data.py:593-654 semantics are built on this by
+ * the Python layer): for each of n_frames (clip, channel, start) triples,
+ * d_spec[f][n_fft/2+1] complex64 = rfft(window * pad_center(x[start : start+frame_length]))
+ * with samples outside [0, n_samples) read as zero.  d_window is float32[n_fft]
+ * (the zero-padded periodic Hann, data.py:627-629).  starts may be negative. */
+int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels,
+                    const int32_t* d_clip, const int32_t* d_channel, const int64_t* d_start,
+                    const int64_t* d_valid_lo, const int64_t* d_valid_hi, int64_t n_frames,
+                    int32_t frame_length, int32_t n_fft, const float* d_window, float* d_spec,
+                    void* stream);
+
+/* FrameExtractor gather (data.py:90-120): d_out[o][c][w] = x[clip][start[o][c] + w][c] */
+int ofp_extract_frames(const float* d_x, int64_t n_samples, int32_t n_channels,
+                       const int64_t* d_start /* [O][C] */, int64_t n_onsets, int32_t width,
+                       float* d_out, void* stream);
+
+/* ---- fingerprint: mel + dB + DCT (data.py:657-680) ------------------------------- */
+/* d_power [n_rows][n_bins] -> d_mel [n_rows][n_mels] = power @ fb^T with the sparse
+ * triangular filterbank given in CSR-by-band form (band b covers bins
+ * [d_fb_lo[b], d_fb_lo[b]+d_fb_len[b]) with weights d_fb_w[d_fb_off[b] ...]). */
+int ofp_mel(const float* d_power, int64_t n_rows, int32_t n_bins, int32_t n_mels,
+            const int32_t* d_fb_lo, const int32_t* d_fb_len, const int32_t* d_fb_off,
+            const float* d_fb_w, float* d_mel, void* stream);
+/* power_to_db (ref 1, amin, top_db relative to the max over the n values) then
+ * DCT-II ortho over the mel axis keeping n_mfcc: d_mel [n_rows][n_mels] ->
+ * d_mfcc [n_rows][n_mfcc].  d_dct is float32 [n_mfcc][n_mels].  top_db < 0: no floor.
+ * d_scratch: >= 4 bytes. */
+int ofp_mfcc(const float* d_mel, int64_t n_rows, int32_t n_mels, int32_t n_mfcc, float amin,
+             float top_db, const float* d_dct, float* d_mfcc, float* d_scratch, void* stream);
+
+/* ---- classifier forward ---------------------------------------------------------- */
+#define OFP_ACT_IDENTITY 0
+#define OFP_ACT_RELU 1
+#define OFP_ACT_SILU 2
+#define OFP_ACT_LEAKYRELU 3
+#define OFP_ACT_ELU 4
+#define OFP_ACT_TANH 5
+/* One fused dense layer: d_y[n][out] = act((d_x[n][in] @ W^T + b) * scale + shift)
+ * (W [out][in] row-major as torch stores Linear.weight; scale/shift fold an eval-mode
+ * BatchNorm1d, NULL = identity; b NULL = no bias).  fp32 MFMA (v_mfma_f32_16x16x4_f32). */
+int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float* d_w,
+              const float* d_b, const float* d_scale, const float* d_shift, int32_t act,
+              float* d_y, void* stream);
+/* Conv1d (stride 1, groups 1) + bias + activation: d_x [n][cin][w] ->
+ * d_y [n][cout][wout], wout = w + 2*padding - dilation*(k-1)   (model.py:84-95) */
+int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w /*[cout][cin][k]*/,
+               const float* d_b, int32_t cout, int32_t k, int32_t padding, int32_t dilation,
+               int32_t act, float* d_y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONSETFP_H */

@@ -1,0 +1,762 @@
+// Amplitude onset detector on gfx950 -- offline (batched, time-parallel) form.
+//
+// Reference behaviour: detection.py:19-86 (driver), :595-888 (detector),
+// envelope_follower.c (followers / tracker / backtracking).  The arithmetic of
+// every step is the single definition in include/ofp_math.h.
+//
+// How a sequential recurrence is made time-parallel WITHOUT changing a bit
+// ("chunk-Jacobi"): the stream of one chain (clip x channel) is cut into chunks;
+// pass 0 runs every chunk from a guessed state after a speculative warm-up of W
+// samples and records the state it actually started the chunk from (`used`) and
+// the state it ended with (`end`).  Pass j >= 1 re-runs exactly those chunks whose
+// recorded start state differs (bitwise) from the end state of the preceding
+// chunk, starting from that end state.  Chunk 0 always starts from the true
+// initial state, so by induction the fixed point of this iteration IS the
+// sequential result; the host stops when a pass changes nothing.  With an
+// adequate warm-up the common case is pass 0 + one verification pass that only
+// compares states.  The worst case degenerates to sequential speed, never to a
+// wrong answer.
+//
+// Stages (each its own chunk-Jacobi loop, in stream order):
+//   hp : 4th-order high-pass IIR (detection.py:743-744)      state z[4]
+//   db : rectified dB with floor (detection.py:747-748)      elementwise
+//   ar : fast & slow attack/release followers (:751)         state (yf, ys)
+//   rel: back to linear + clip (:753-754)                    elementwise
+//   mm : EMA min/max tracker (:762) -> thresholds per block  state (mn, mx)
+//   scan + state machine: threshold crossings, hysteresis, cooldown (:764-797)
+//   backtrack (:800-825)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ofp_math.h"
+#include "ofp_common.h"
+
+#include "ofp_detector.h"
+
+namespace {
+
+using ofp::align_up;
+using ofp::cdiv;
+
+// ---------------------------------------------------------------------------
+// stream geometry of one clip (all in samples)
+struct Geom {
+    int64_t N;     // samples per clip
+    int64_t Nm;    // floor(N/B)*B main samples
+    int64_t n_w;   // warm samples through the high-pass (detection.py:70,828-829)
+    int64_t n_wb;  // warm samples through followers/tracker: full blocks only (:832-834)
+    int64_t U;     // follower stream length n_wb + Nm
+    int64_t V;     // high-pass stream length n_w + Nm
+    int32_t C, B;
+};
+
+__host__ __device__ inline int64_t hp_src(const Geom& g, int64_t v) { return v < g.n_w ? v : v - g.n_w; }
+__host__ __device__ inline int64_t hp_dst(const Geom& g, int64_t v) {
+    return v < g.n_wb ? v : (v >= g.n_w ? v - g.n_w + g.n_wb : -1);
+}
+__host__ __device__ inline int64_t u_src(const Geom& g, int64_t u) { return u < g.n_wb ? u : u - g.n_wb; }
+
+// ---------------------------------------------------------------------------
+// stages
+struct HpStage {
+    static constexpr int NS = 4;
+    struct State { float z[4]; };
+    Geom g;
+    const float* x;  // [clips][N][C]
+    float* out;      // [clips][U][C]
+    float b[5], a[5];
+    int64_t L, W, n_chunks;
+    __device__ int64_t len() const { return g.V; }
+    __device__ State init(int64_t, int) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
+    __device__ State guess(int64_t, int, int64_t) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
+    __device__ float load(int64_t clip, int c, int64_t v) const {
+        return x[(clip * g.N + hp_src(g, v)) * g.C + c];
+    }
+    template <bool OUT>
+    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t v) const {
+        float y = ofp_df2t4_step(xv, b, a, s.z);
+        if (OUT) {
+            int64_t u = hp_dst(g, v);
+            if (u >= 0) out[(clip * g.U + u) * g.C + c] = y;
+        }
+    }
+};
+
+struct ArStage {
+    static constexpr int NS = 2;
+    struct State { float z[2]; };  // yf, ys
+    Geom g;
+    const float* xdb;  // [clips][U][C]
+    float* dif;        // [clips][U][C]
+    float fa, fr, sa, sr, floor_db;
+    int64_t L, W, n_chunks;
+    __device__ int64_t len() const { return g.U; }
+    __device__ State init(int64_t, int) const { return State{{floor_db, floor_db}}; }
+    __device__ State guess(int64_t clip, int c, int64_t u) const {
+        float v = load(clip, c, u);
+        return State{{v, v}};
+    }
+    __device__ float load(int64_t clip, int c, int64_t u) const { return xdb[(clip * g.U + u) * g.C + c]; }
+    template <bool OUT>
+    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t u) const {
+        s.z[0] = ofp_ar_step(xv, s.z[0], fa, fr);
+        s.z[1] = ofp_ar_step(xv, s.z[1], sa, sr);
+        if (OUT) dif[(clip * g.U + u) * g.C + c] = s.z[0] - s.z[1];
+    }
+};
+
+struct MmStage {
+    static constexpr int NS = 2;
+    struct State { float z[2]; };  // mn, mx
+    Geom g;
+    const float* rel;  // [clips][U][C]
+    float* thr_mn;     // [clips][nb][C] tracker state after each MAIN block
+    float* thr_mx;
+    float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
+    int64_t nb;
+    int64_t L, W, n_chunks;
+    __device__ int64_t len() const { return g.U; }
+    __device__ State init(int64_t, int) const { return State{{min0, max0}}; }
+    __device__ State guess(int64_t, int, int64_t) const { return State{{minmin, 0.f}}; }
+    __device__ float load(int64_t clip, int c, int64_t u) const { return rel[(clip * g.U + u) * g.C + c]; }
+    template <bool OUT>
+    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t u) const {
+        s.z[0] = ofp_min_step(xv, s.z[0], ialpha_min, alpha_min, minmin);
+        s.z[1] = ofp_max_step(xv, s.z[1], ialpha_max, alpha_max);
+        if (OUT) {
+            int64_t m = u - g.n_wb;
+            if (m >= 0 && (m + 1) % g.B == 0) {
+                int64_t j = m / g.B;
+                thr_mn[(clip * nb + j) * g.C + c] = s.z[0];
+                thr_mx[(clip * nb + j) * g.C + c] = s.z[1];
+            }
+        }
+    }
+};
+
+// run t in [t0, t1) with register prefetch of the (state-independent) inputs
+template <class S, bool OUT>
+__device__ __forceinline__ void run_span(const S& st, typename S::State& s, int64_t clip, int c,
+                                         int64_t t0, int64_t t1) {
+    constexpr int PB = 8;
+    float cur[PB], nxt[PB];
+    int64_t t = t0;
+    if (t + PB <= t1) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) cur[i] = st.load(clip, c, t + i);
+        while (t + 2 * PB <= t1) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) nxt[i] = st.load(clip, c, t + PB + i);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) st.template step<OUT>(s, cur[i], clip, c, t + i);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) cur[i] = nxt[i];
+            t += PB;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) st.template step<OUT>(s, cur[i], clip, c, t + i);
+        t += PB;
+    }
+    for (; t < t1; ++t) st.template step<OUT>(s, st.load(clip, c, t), clip, c, t);
+}
+
+// One chunk-Jacobi pass.  Thread = (clip, chunk, channel), channel fastest.
+// State words are compared and stored as raw bits (NaN-safe).
+template <class S>
+__global__ __launch_bounds__(64) void k_jacobi(S st, int pass, int64_t n_threads,
+                                               const uint32_t* __restrict__ end_prev,
+                                               uint32_t* __restrict__ end_next,
+                                               uint32_t* __restrict__ used, int* changed) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int C = st.g.C;
+    const int c = (int)(id % C);
+    const int64_t r = id / C;
+    const int64_t k = r % st.n_chunks;
+    const int64_t clip = r / st.n_chunks;
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.len());
+    const int64_t sidx = ((clip * st.n_chunks + k) * C + c) * S::NS;
+    typename S::State s;
+    if (pass == 0) {
+        int64_t ws = start - st.W;
+        if (ws <= 0) {
+            ws = 0;
+            s = st.init(clip, c);
+        } else {
+            s = st.guess(clip, c, ws);
+        }
+        run_span<S, false>(st, s, clip, c, ws, start);
+#pragma unroll
+        for (int i = 0; i < S::NS; ++i) used[sidx + i] = ofp_f2u(s.z[i]);
+        run_span<S, true>(st, s, clip, c, start, end);
+#pragma unroll
+        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = ofp_f2u(s.z[i]);
+        return;
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = end_prev[sidx + i];
+        return;
+    }
+    const int64_t pidx = sidx - (int64_t)C * S::NS;  // chunk k-1, same clip and channel
+    bool same = true;
+    uint32_t in[S::NS];
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+        in[i] = end_prev[pidx + i];
+        same &= (in[i] == used[sidx + i]);
+    }
+    if (same) {
+#pragma unroll
+        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = end_prev[sidx + i];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+        s.z[i] = ofp_u2f(in[i]);
+        used[sidx + i] = in[i];
+    }
+    run_span<S, true>(st, s, clip, c, start, end);
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = ofp_f2u(s.z[i]);
+    atomicAdd(changed, 1);
+}
+
+// ---- elementwise stages ----------------------------------------------------
+// rectified dB (detection.py:747-748).  from_x: no high-pass, read the audio
+// through the stream mapping; else in place on the filtered buffer.
+__global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict__ x,
+                                                 float* __restrict__ buf, int64_t n_clips,
+                                                 int from_x, float floor_db) {
+    const int64_t per_clip = g.U * g.C;
+    const int64_t total = n_clips * per_clip;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (from_x) {
+            int64_t clip = i / per_clip, rem = i % per_clip;
+            int64_t u = rem / g.C;
+            int c = (int)(rem % g.C);
+            v = x[(clip * g.N + u_src(g, u)) * g.C + c];
+        } else {
+            v = buf[i];
+        }
+        buf[i] = ofp_rect_db(v, floor_db);
+    }
+}
+
+// back to linear (detection.py:753-754), in place; main part also to the caller's rel
+__global__ __launch_bounds__(256) void k_rel_linear(Geom g, float* __restrict__ buf,
+                                                    float* __restrict__ rel_out, int64_t n_clips,
+                                                    float floor_db) {
+    const int64_t per_clip = g.U * g.C;
+    const int64_t total = n_clips * per_clip;
+    const int64_t warm = g.n_wb * g.C;
+    const int64_t main = g.Nm * g.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float v = ofp_rel_linear(buf[i], floor_db);
+        buf[i] = v;
+        if (rel_out) {
+            int64_t clip = i / per_clip, rem = i % per_clip;
+            if (rem >= warm) rel_out[clip * main + (rem - warm)] = v;
+        }
+    }
+}
+
+// ---- block scan: first upward crossing and last sample below `off`, per
+// (clip, main block, channel) -- everything of detection.py:759-770,784-790 that
+// does not depend on the hysteresis state.
+struct ScanArgs {
+    Geom g;
+    const float* rel;  // [clips][U][C]
+    const float* thr_mn;
+    const float* thr_mx;  // [clips][nb][C] (relative mode)
+    const float* on_f;
+    const float* off_f;
+    const double* on_d;
+    int manual;
+    int64_t nb, n_clips;
+    int32_t* first_cross;  // [clips][nb][C]: index or -1
+    int32_t* last_below;   // [clips][nb][C]: index or -1
+};
+
+__global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
+    const int C = a.g.C, B = a.g.B;
+    const int64_t total = a.n_clips * a.nb * C;
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int c = (int)(id % C);
+    const int64_t j = (id / C) % a.nb;
+    const int64_t clip = id / ((int64_t)C * a.nb);
+    float on, off;
+    double on0;
+    if (a.manual) {
+        on = a.on_f[c];
+        on0 = a.on_d[c];
+        off = a.off_f[c];
+    } else {
+        float mn = a.thr_mn[id], mx = a.thr_mx[id];
+        float t1 = mx * a.on_f[c];
+        on = t1 + mn;  // detection.py:763
+        on0 = (double)on;
+        float t2 = mx * a.off_f[c];
+        off = t2 + mn;  // detection.py:787
+    }
+    const float* r = a.rel + (clip * a.g.U + a.g.n_wb + j * B) * C + c;
+    // detection.py:769: row 0 compares prev_values (float64 copy of the previous
+    // block's last row; zeros before the first main block) with the threshold
+    float prev = (j == 0) ? 0.0f : r[-C];
+    bool below_before = (double)prev < on0;
+    int first = -1, last = -1;
+    for (int t = 0; t < B; ++t) {
+        float v = r[(int64_t)t * C];
+        if (first < 0 && v > on && below_before) first = t;
+        if (v < off) last = t;
+        below_before = v < on;
+    }
+    a.first_cross[id] = first;
+    a.last_below[id] = last;
+}
+
+// ---- hysteresis / cooldown state machine over the blocks of one clip
+// (detection.py:764-797).  One 64-lane wave per clip, lanes over channels.
+struct SmArgs {
+    Geom g;
+    int64_t nb, n_clips, cap, cooldown;
+    const int32_t* first_cross;
+    const int32_t* last_below;
+    ofp_onset* records;  // [clips][cap]
+    int64_t* counts;     // [clips]
+    int32_t clip_base;   // added to record.clip
+};
+
+__global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
+    extern __shared__ unsigned char smem[];
+    const int C = a.g.C, B = a.g.B;
+    const int64_t clip = blockIdx.x;
+    const int lane = threadIdx.x;
+    // per-channel state in LDS (C may exceed 64)
+    int64_t* deb = reinterpret_cast<int64_t*>(smem);          // [C]
+    int32_t* onidx = reinterpret_cast<int32_t*>(deb + C);     // [C]
+    uint8_t* state = reinterpret_cast<uint8_t*>(onidx + C);   // [C]
+    uint8_t* onflag = state + C;                              // [C]
+    for (int c = lane; c < C; c += 64) {
+        deb[c] = 0;
+        state[c] = 0;
+    }
+    __syncthreads();
+    int64_t count = 0;
+    ofp_onset* rec = a.records + clip * a.cap;
+    for (int64_t j = 0; j < a.nb; ++j) {
+        const int32_t* fc = a.first_cross + (clip * a.nb + j) * C;
+        const int32_t* lb = a.last_below + (clip * a.nb + j) * C;
+        int mx = 0;
+        for (int c = lane; c < C; c += 64) {
+            int f = fc[c];
+            bool gate = !state[c] && deb[c] < 1;      // :764-768 (block-start values)
+            bool on = gate && f >= 0;
+            onflag[c] = on;
+            int oi = on ? f : 0;                      // :774 argmax of an all-False column is 0
+            onidx[c] = oi;
+            mx = max(mx, oi);
+        }
+        // :790 on_indices.max() over ALL channels
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            int c = c0 + lane;
+            bool on = false;
+            if (c < C) {
+                on = onflag[c];
+                if (on) {                              // :778-779
+                    state[c] = 1;
+                    deb[c] = a.cooldown;
+                }
+                if (deb[c] > 0) deb[c] -= B;           // :780
+                if (lb[c] >= mx) state[c] = 0;         // :784-791 (any row >= mx below off)
+            }
+            unsigned long long m = __ballot(on);
+            if (on) {
+                int64_t pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < a.cap) {
+                    rec[pos].clip = (int32_t)clip + a.clip_base;
+                    rec[pos].channel = c;
+                    rec[pos].sample = j * B + onidx[c];  // detection.py:80
+                }
+            }
+            count += __popcll(m);
+        }
+    }
+    if (lane == 0) a.counts[clip] = count;
+}
+
+// ---- backtracking (detection.py:800-825 == envelope_follower.c:59-85), one
+// thread per onset.  The ring buffer of the reference (last N rows after writing
+// the current block) is a window of the main relative envelope; rows before the
+// stream start read as zero.
+struct BtArgs {
+    Geom g;
+    const float* rel;  // [clips][U][C]
+    ofp_onset* records;
+    const int64_t* counts;
+    int64_t cap, n_clips, N;  // N = backtrack_buffer_size
+    float alpha, tol;
+    int32_t clip_base;
+};
+
+__device__ __forceinline__ float bt_at(const BtArgs& a, int64_t clip, int64_t block_end, int64_t i, int c) {
+    int64_t m = block_end - i;  // buffer[-i]
+    if (m < 0 || i > a.N) return 0.0f;  // outside the N-row window / before the stream
+    return a.rel[(clip * a.g.U + a.g.n_wb + m) * a.g.C + c];
+}
+
+__global__ __launch_bounds__(64) void k_backtrack(BtArgs a) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t clip = id / a.cap, k = id % a.cap;
+    if (clip >= a.n_clips) return;
+    int64_t n = min(a.counts[clip], a.cap);
+    if (k >= n) return;
+    ofp_onset& r = a.records[clip * a.cap + k];
+    const int B = a.g.B;
+    const int c = r.channel;
+    int64_t j = r.sample / B;
+    int64_t delta = r.sample % B;
+    int64_t block_end = (j + 1) * B;
+    float omba = (float)(1.0 - (double)a.alpha);
+    int64_t i = B - delta;
+    float cur = bt_at(a, clip, block_end, i, c);
+    i += 1;
+    float prev = bt_at(a, clip, block_end, i, c);
+    float ps = a.alpha * prev + omba * cur;
+    while (cur > ps && fabsf(ps - prev) > a.tol && (i + 1 < a.N)) {
+        delta -= 1;
+        i += 1;
+        cur = ps;
+        prev = bt_at(a, clip, block_end, i, c);
+        ps = a.alpha * prev + omba * cur;
+    }
+    r.sample = j * B + delta;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+struct Layout {
+    Geom g;
+    int64_t nb;
+    int64_t hp_L, hp_W, hp_chunks;
+    int64_t ar_L, ar_W, ar_chunks;
+    int64_t mm_L, mm_W, mm_chunks;
+    // byte offsets
+    int64_t o_xdb, o_dif, o_hp_state, o_ar_state, o_mm_state, o_thr_mn, o_thr_mx, o_first,
+        o_last, o_flags, total;
+};
+
+int64_t pick(int64_t user, int64_t dflt) { return user > 0 ? user : dflt; }
+
+Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t warm) {
+    Layout l;
+    const auto& p = d->p;
+    Geom& g = l.g;
+    g.C = p.n_channels;
+    g.B = p.block_size;
+    g.N = N;
+    g.Nm = (N / g.B) * g.B;
+    g.n_w = std::max<int64_t>(0, std::min(warm, N));
+    g.n_wb = (g.n_w / g.B) * g.B;
+    g.U = g.n_wb + g.Nm;
+    g.V = g.n_w + g.Nm;
+    l.nb = g.Nm / g.B;
+    // longest follower time constant in samples (coefficient = 1/samples)
+    float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
+    double tau = cmin > 0 ? 1.0 / cmin : 1.0;
+    int64_t ar_w_default = align_up((int64_t)std::min(20.0 * tau + 1024.0, 4.0e6), 1024);
+    l.hp_L = pick(d->t.hp_chunk, 4096);
+    l.hp_W = d->t.hp_warm > 0 ? d->t.hp_warm : (d->t.hp_warm < 0 ? 0 : 32768);
+    l.ar_L = pick(d->t.ar_chunk, 4096);
+    l.ar_W = d->t.ar_warm > 0 ? d->t.ar_warm : (d->t.ar_warm < 0 ? 0 : ar_w_default);
+    l.mm_L = pick(d->t.mm_chunk, 8192);
+    l.mm_W = d->t.mm_warm > 0 ? d->t.mm_warm : (d->t.mm_warm < 0 ? 0 : 98304);
+    l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
+    l.ar_chunks = std::max<int64_t>(1, cdiv(g.U, l.ar_L));
+    l.mm_chunks = std::max<int64_t>(1, cdiv(g.U, l.mm_L));
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t r = o;
+        o += align_up(bytes, 256);
+        return r;
+    };
+    const int64_t stream = n_clips * g.U * g.C * 4;
+    l.o_xdb = take(stream);
+    l.o_dif = take(stream);
+    l.o_hp_state = take(3 * n_clips * l.hp_chunks * g.C * 4 * 4);
+    l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
+    l.o_mm_state = take(3 * n_clips * l.mm_chunks * g.C * 2 * 4);
+    l.o_thr_mn = take(n_clips * l.nb * g.C * 4);
+    l.o_thr_mx = take(n_clips * l.nb * g.C * 4);
+    l.o_first = take(n_clips * l.nb * g.C * 4);
+    l.o_last = take(n_clips * l.nb * g.C * 4);
+    l.o_flags = take(256);
+    l.total = o;
+    return l;
+}
+
+// chunk-Jacobi driver for one stage; returns passes run (>=1) or a negative error
+template <class S>
+int run_stage(const char* name, S st, int64_t n_clips, unsigned char* ws, int64_t o_state,
+              int* d_changed, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
+    const int64_t n_threads = n_clips * st.n_chunks * st.g.C;
+    const int64_t words = n_threads * S::NS;
+    uint32_t* used = reinterpret_cast<uint32_t*>(ws + o_state);
+    uint32_t* endA = used + words;
+    uint32_t* endB = endA + words;
+    const int block = 64;
+    const unsigned grid = (unsigned)cdiv(n_threads, block);
+    hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(block), 0, stream, st, 0, n_threads,
+                       (const uint32_t*)endB, endA, used, d_changed);
+    OFP_LAUNCH_CHECK(name);
+    *passes = 1;
+    if (st.n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
+    uint32_t* prev = endA;
+    uint32_t* next = endB;
+    for (int pass = 1;; ++pass) {
+        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(block), 0, stream, st, pass, n_threads,
+                           (const uint32_t*)prev, next, used, d_changed);
+        OFP_LAUNCH_CHECK(name);
+        int changed = 0;
+        OFP_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+        OFP_HIP(hipStreamSynchronize(stream));
+        *passes += 1;
+        std::swap(prev, next);
+        if (changed == 0) break;
+        *repaired += changed;
+        if (max_passes > 0 && pass >= max_passes)
+            return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name,
+                             changed, pass);
+    }
+    return OFP_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold,
+                        const double* off_threshold, ofp_detector** out) {
+    OFP_REQUIRE(p && on_threshold && off_threshold && out, "ofp_detector_create: NULL argument");
+    OFP_REQUIRE(p->n_channels >= 1 && p->n_channels <= 4096, "n_channels %d out of range [1,4096]",
+                p->n_channels);
+    OFP_REQUIRE(p->block_size >= 1 && p->block_size <= (1 << 20), "block_size %d out of range",
+                p->block_size);
+    OFP_REQUIRE(!p->backtrack || p->backtrack_buffer_size >= p->block_size,
+                "backtrack_buffer_size should be at least block_size!");
+    OFP_REQUIRE(!p->hp_enabled || p->hp_a[0] != 0.0f, "hp_a[0] must be non-zero");
+    ofp_detector* d = new (std::nothrow) ofp_detector();
+    if (!d) return ofp::fail(OFP_ERR_INVALID, "out of host memory");
+    d->p = *p;
+    std::memset(&d->t, 0, sizeof(d->t));
+    for (int k = 0; k < 5; ++k) {
+        d->b[k] = p->hp_enabled ? p->hp_b[k] / p->hp_a[0] : 0.0f;
+        d->a[k] = p->hp_enabled ? p->hp_a[k] / p->hp_a[0] : 0.0f;
+    }
+    d->ialpha_min = ofp_ialpha(p->alpha_min);
+    d->ialpha_max = ofp_ialpha(p->alpha_max);
+    const int C = p->n_channels;
+    d->on.assign(on_threshold, on_threshold + C);
+    d->off.assign(off_threshold, off_threshold + C);
+    std::vector<float> onf(C), offf(C);
+    for (int c = 0; c < C; ++c) {
+        onf[c] = (float)on_threshold[c];
+        offf[c] = (float)off_threshold[c];
+    }
+    hipError_t e = hipMalloc(&d->d_on_f, C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d->d_off_f, C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d->d_on_d, C * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d->d_on_f, onf.data(), C * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ofp_detector_destroy(d);
+        return ofp::fail(OFP_ERR_HIP, "ofp_detector_create: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return OFP_OK;
+}
+
+int ofp_detector_destroy(ofp_detector* d) {
+    if (!d) return OFP_OK;
+    if (d->d_on_f) (void)hipFree(d->d_on_f);
+    if (d->d_off_f) (void)hipFree(d->d_off_f);
+    if (d->d_on_d) (void)hipFree(d->d_on_d);
+    delete d;
+    return OFP_OK;
+}
+
+int ofp_detector_set_tuning(ofp_detector* d, const ofp_detect_tuning* t) {
+    OFP_REQUIRE(d && t, "ofp_detector_set_tuning: NULL argument");
+    d->t = *t;
+    return OFP_OK;
+}
+
+int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64_t n_samples,
+                                   int64_t warm) {
+    if (!d || n_clips < 0 || n_samples < 0) return -1;
+    return make_layout(d, n_clips, n_samples, warm).total;
+}
+
+int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
+                       float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts,
+                       void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_) {
+    OFP_REQUIRE(d && d_counts && d_ws, "ofp_detect_offline: NULL argument");
+    OFP_REQUIRE(n_clips >= 1 && N >= 0 && cap >= 0, "ofp_detect_offline: bad sizes");
+    OFP_REQUIRE(d_x || N == 0, "ofp_detect_offline: d_x is NULL");
+    OFP_REQUIRE(d_records || cap == 0, "ofp_detect_offline: d_records is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    const Layout l = make_layout(d, n_clips, N, warm);
+    if (ws_bytes < l.total)
+        return ofp::fail(OFP_ERR_WORKSPACE, "work space %lld < required %lld bytes", (long long)ws_bytes,
+                         (long long)l.total);
+    const Geom& g = l.g;
+    const auto& p = d->p;
+    unsigned char* ws = static_cast<unsigned char*>(d_ws);
+    float* xdb = reinterpret_cast<float*>(ws + l.o_xdb);
+    float* dif = reinterpret_cast<float*>(ws + l.o_dif);
+    int* d_changed = reinterpret_cast<int*>(ws + l.o_flags);
+    int64_t info[4] = {0, 0, 0, 0};
+    if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
+        OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
+        OFP_HIP(hipStreamSynchronize(stream));
+        if (h_info) std::memcpy(h_info, info, sizeof(info));
+        return OFP_OK;
+    }
+    const int64_t n_elem = n_clips * g.U * g.C;
+    const unsigned ew_grid = (unsigned)std::min<int64_t>(cdiv(n_elem, 256), 256 * 16);
+
+    // --- hp + dB
+    if (p.hp_enabled) {
+        HpStage st;
+        st.g = g;
+        st.x = d_x;
+        st.out = xdb;
+        std::memcpy(st.b, d->b, sizeof(st.b));
+        std::memcpy(st.a, d->a, sizeof(st.a));
+        st.L = l.hp_L;
+        st.W = l.hp_W;
+        st.n_chunks = l.hp_chunks;
+        int rc = run_stage("hp stage", st, n_clips, ws, l.o_hp_state, d_changed, d->t.max_passes, stream,
+                           &info[0], &info[3]);
+        if (rc != OFP_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, d_x, xdb, n_clips,
+                       p.hp_enabled ? 0 : 1, p.floor_db);
+    OFP_LAUNCH_CHECK("k_rect_db");
+
+    // --- followers
+    {
+        ArStage st;
+        st.g = g;
+        st.xdb = xdb;
+        st.dif = dif;
+        st.fa = p.fast_attack;
+        st.fr = p.fast_release;
+        st.sa = p.slow_attack;
+        st.sr = p.slow_release;
+        st.floor_db = p.floor_db;
+        st.L = l.ar_L;
+        st.W = l.ar_W;
+        st.n_chunks = l.ar_chunks;
+        int rc = run_stage("follower stage", st, n_clips, ws, l.o_ar_state, d_changed, d->t.max_passes,
+                           stream, &info[1], &info[3]);
+        if (rc != OFP_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_rel_linear, dim3(ew_grid), dim3(256), 0, stream, g, dif, d_rel, n_clips,
+                       p.floor_db);
+    OFP_LAUNCH_CHECK("k_rel_linear");
+    const float* rel = dif;
+
+    // --- tracker (relative thresholds only; in manual mode its state is never read)
+    float* thr_mn = reinterpret_cast<float*>(ws + l.o_thr_mn);
+    float* thr_mx = reinterpret_cast<float*>(ws + l.o_thr_mx);
+    if (!p.manual) {
+        MmStage st;
+        st.g = g;
+        st.rel = rel;
+        st.thr_mn = thr_mn;
+        st.thr_mx = thr_mx;
+        st.alpha_min = p.alpha_min;
+        st.alpha_max = p.alpha_max;
+        st.ialpha_min = d->ialpha_min;
+        st.ialpha_max = d->ialpha_max;
+        st.minmin = p.minmin;
+        st.min0 = p.min0;
+        st.max0 = p.max0;
+        st.nb = l.nb;
+        st.L = l.mm_L;
+        st.W = l.mm_W;
+        st.n_chunks = l.mm_chunks;
+        int rc = run_stage("tracker stage", st, n_clips, ws, l.o_mm_state, d_changed, d->t.max_passes,
+                           stream, &info[2], &info[3]);
+        if (rc != OFP_OK) return rc;
+    }
+
+    // --- crossings per block, then the hysteresis state machine
+    ScanArgs sa;
+    sa.g = g;
+    sa.rel = rel;
+    sa.thr_mn = thr_mn;
+    sa.thr_mx = thr_mx;
+    sa.on_f = d->d_on_f;
+    sa.off_f = d->d_off_f;
+    sa.on_d = d->d_on_d;
+    sa.manual = p.manual;
+    sa.nb = l.nb;
+    sa.n_clips = n_clips;
+    sa.first_cross = reinterpret_cast<int32_t*>(ws + l.o_first);
+    sa.last_below = reinterpret_cast<int32_t*>(ws + l.o_last);
+    {
+        int64_t total = n_clips * l.nb * g.C;
+        hipLaunchKernelGGL(k_block_scan, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, sa);
+        OFP_LAUNCH_CHECK("k_block_scan");
+    }
+    SmArgs sm;
+    sm.g = g;
+    sm.nb = l.nb;
+    sm.n_clips = n_clips;
+    sm.cap = cap;
+    sm.cooldown = p.cooldown;
+    sm.first_cross = sa.first_cross;
+    sm.last_below = sa.last_below;
+    sm.records = d_records;
+    sm.counts = d_counts;
+    sm.clip_base = 0;
+    {
+        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + 16;
+        hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
+        OFP_LAUNCH_CHECK("k_state_machine");
+    }
+    if (p.backtrack && cap > 0) {
+        BtArgs bt;
+        bt.g = g;
+        bt.rel = rel;
+        bt.records = d_records;
+        bt.counts = d_counts;
+        bt.cap = cap;
+        bt.n_clips = n_clips;
+        bt.N = p.backtrack_buffer_size;
+        bt.alpha = p.backtrack_alpha;
+        bt.tol = p.backtrack_tol;
+        bt.clip_base = 0;
+        hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
+        OFP_LAUNCH_CHECK("k_backtrack");
+    }
+    OFP_HIP(hipStreamSynchronize(stream));
+    if (h_info) std::memcpy(h_info, info, sizeof(info));
+    return OFP_OK;
+}
+
+}  // extern "C"

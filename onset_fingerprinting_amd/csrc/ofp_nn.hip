@@ -1,0 +1,126 @@
+// Classifier forward passes on gfx950: fused dense layer on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain) and a direct
+// Conv1d + activation.  Reference: calibration.py:463-527 (FCNN, eval mode,
+// BatchNorm1d folded into scale/shift by the host), model.py:52-120 (CNN).
+#include "ofp_common.h"
+
+namespace {
+
+using ofp::cdiv;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float activate(float v, int act) {
+    switch (act) {
+        case OFP_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case OFP_ACT_SILU: return v / (1.0f + expf(-v));
+        case OFP_ACT_LEAKYRELU: return v >= 0.0f ? v : 0.01f * v;
+        case OFP_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+        case OFP_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// One wave computes a 16-row x 16-column output tile per MFMA chain.
+// A fragment: lane l holds x[row0 + (l&15)][k0 + (l>>4)]
+// B fragment: lane l holds W[col0 + (l&15)][k0 + (l>>4)]   (B[k][j] = W[j][k])
+// C/D: acc[r] is row (l>>4)*4 + r, column l&15.
+__global__ __launch_bounds__(256) void k_dense(const float* __restrict__ x, int64_t n, int in, int out,
+                                               const float* __restrict__ w, const float* __restrict__ b,
+                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                               int act, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t row_tiles = cdiv(n, 16);
+    const int col_tiles = (out + 15) / 16;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int64_t rt = wave; rt < row_tiles; rt += n_waves) {
+        const int64_t arow = rt * 16 + li;
+        const float* xr = x + arow * in;
+        const bool arow_ok = arow < n;
+        for (int ct = 0; ct < col_tiles; ++ct) {
+            const int bcol = ct * 16 + li;
+            const float* wr = w + (int64_t)bcol * in;
+            const bool bcol_ok = bcol < out;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < in; k0 += 4) {
+                const int k = k0 + lk;
+                float a = (arow_ok && k < in) ? xr[k] : 0.0f;
+                float bb = (bcol_ok && k < in) ? wr[k] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
+            }
+            const int col = ct * 16 + li;
+            if (col < out) {
+                const float bias = b ? b[col] : 0.0f;
+                const float sc = scale ? scale[col] : 1.0f;
+                const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = rt * 16 + lk * 4 + r;
+                    if (row < n) y[row * out + col] = activate((acc[r] + bias) * sc + sh, act);
+                }
+            }
+        }
+    }
+}
+
+// Conv1d, stride 1, groups 1: thread per output element
+__global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int64_t n, int cin, int w,
+                                                const float* __restrict__ wt, const float* __restrict__ b,
+                                                int cout, int k, int padding, int dilation, int act,
+                                                int wout, float* __restrict__ y) {
+    const int64_t total = n * cout * wout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % wout);
+        const int64_t t = i / wout;
+        const int o = (int)(t % cout);
+        const int64_t s = t / cout;
+        float acc = b ? b[o] : 0.0f;
+        const float* xs = x + s * cin * w;
+        const float* ws = wt + (int64_t)o * cin * k;
+        for (int ci = 0; ci < cin; ++ci) {
+            for (int kk = 0; kk < k; ++kk) {
+                int q = p - padding + kk * dilation;
+                if (q >= 0 && q < w) acc = fmaf(xs[(int64_t)ci * w + q], ws[ci * k + kk], acc);
+            }
+        }
+        y[i] = activate(acc, act);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float* d_w, const float* d_b,
+              const float* d_scale, const float* d_shift, int32_t act, float* d_y, void* stream) {
+    if (n == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_w && d_y, "ofp_dense: NULL argument");
+    OFP_REQUIRE(in >= 1 && out >= 1 && n > 0, "ofp_dense: bad sizes");
+    OFP_REQUIRE(act >= OFP_ACT_IDENTITY && act <= OFP_ACT_TANH, "ofp_dense: unknown activation %d", act);
+    int64_t row_tiles = cdiv(n, 16);
+    unsigned grid = (unsigned)std::min<int64_t>(cdiv(row_tiles, 4), 256 * 8);
+    hipLaunchKernelGGL(k_dense, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n, in, out, d_w, d_b,
+                       d_scale, d_shift, act, d_y);
+    OFP_LAUNCH_CHECK("k_dense");
+    return OFP_OK;
+}
+
+int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w, const float* d_b,
+               int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t act, float* d_y,
+               void* stream) {
+    if (n == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_w && d_y, "ofp_conv1d: NULL argument");
+    int wout = w + 2 * padding - dilation * (k - 1);
+    OFP_REQUIRE(wout >= 1, "ofp_conv1d: empty output (w=%d k=%d padding=%d dilation=%d)", w, k, padding, dilation);
+    OFP_REQUIRE(act >= OFP_ACT_IDENTITY && act <= OFP_ACT_TANH, "ofp_conv1d: unknown activation %d", act);
+    int64_t total = n * cout * wout;
+    unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_conv1d, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n, cin, w, d_w, d_b, cout,
+                       k, padding, dilation, act, wout, d_y);
+    OFP_LAUNCH_CHECK("k_conv1d");
+    return OFP_OK;
+}
+
+}  // extern "C"

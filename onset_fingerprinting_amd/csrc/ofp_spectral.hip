@@ -1,0 +1,464 @@
+// Framing + Hann window + real FFT (+ power, mel, MFCC) on gfx950.
+//
+// Reference behaviour: data.py:581-654 (stft_frame / stft: float64 periodic Hann
+// times the frame, np.fft.rfft, stored as complex64), data.py:657-680 (mel, dB,
+// DCT through librosa), data.py:90-120 (FrameExtractor gather).
+//
+// FFT structure: an F-point real FFT is an M = F/2 point complex FFT of the
+// packed sequence z[n] = x[2n] + i x[2n+1] followed by one split pass.  The
+// complex FFT is a Stockham autosort FFT with radix-8/4 passes through two LDS
+// buffers; the twiddles W_M^k, the split twiddles W_F^k and the window are built
+// once per workgroup in LDS (in fp64, rounded once) and reused for every frame
+// the workgroup processes.  T = M/8 lanes cooperate on one frame, so a 1024-point
+// frame is exactly one 64-lane wavefront.
+#include <cmath>
+
+#include "ofp_common.h"
+
+namespace {
+
+using ofp::cdiv;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+__device__ __forceinline__ void dft2(float2& a, float2& b) {
+    float2 t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+__device__ __forceinline__ void dft4(float2* v) {  // outputs in natural order
+    dft2(v[0], v[2]);
+    dft2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    float2 t = v[1];
+    v[1] = v[2];
+    v[2] = t;
+}
+__device__ __forceinline__ void dft8(float2* v) {  // outputs in natural order
+    const float h = 0.70710678118654752440f;
+    dft2(v[0], v[4]);
+    dft2(v[1], v[5]);
+    dft2(v[2], v[6]);
+    dft2(v[3], v[7]);
+    v[5] = make_float2((v[5].x + v[5].y) * h, (v[5].y - v[5].x) * h);   // * W8^1
+    v[6] = mul_mi(v[6]);                                                 // * W8^2
+    v[7] = make_float2((v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h);  // * W8^3
+    dft2(v[0], v[2]);
+    dft2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    dft2(v[4], v[6]);
+    dft2(v[5], v[7]);
+    v[7] = mul_mi(v[7]);
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    dft2(v[4], v[5]);
+    dft2(v[6], v[7]);
+    // bit-reversed -> natural
+    float2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[6]; v[6] = t;
+}
+
+template <int R>
+__device__ __forceinline__ void dftR(float2* v) {
+    if (R == 8) dft8(v);
+    else if (R == 4) dft4(v);
+    else dft2(v[0], v[1]);
+}
+
+// one Stockham pass of radix R: M points, Ns = product of the radices already done
+template <int R, int M, int T>
+__device__ __forceinline__ void fft_pass(const float2* in, float2* out, const float2* tw, int Ns, int tid) {
+#pragma unroll 1
+    for (int j = tid; j < M / R; j += T) {
+        const int k = j & (Ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = in[j + i * (M / R)];
+        const int tstep = k * (M / (Ns * R));
+#pragma unroll
+        for (int i = 1; i < R; ++i) v[i] = cmul(v[i], tw[(i * tstep) & (M - 1)]);
+        dftR<R>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int i = 0; i < R; ++i) out[j0 + i * Ns] = v[i];
+    }
+}
+
+template <int M> struct Radices;
+template <> struct Radices<128>  { static constexpr int n = 3; static constexpr int r[4] = {8, 4, 4, 1}; };
+template <> struct Radices<256>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 4, 1}; };
+template <> struct Radices<512>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
+template <> struct Radices<1024> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
+template <> struct Radices<2048> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
+
+// complex FFT of the M points in bufA (all T lanes of the frame group call this
+// together; `sync` is a workgroup barrier).  Returns the buffer holding the result.
+template <int M, int T>
+__device__ __forceinline__ float2* cfft(float2* a, float2* b, const float2* tw, int tid) {
+    using Rx = Radices<M>;
+    int Ns = 1;
+#pragma unroll
+    for (int p = 0; p < Rx::n; ++p) {
+        __syncthreads();
+        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, b, tw, Ns, tid);
+        else fft_pass<4, M, T>(a, b, tw, Ns, tid);
+        Ns *= Rx::r[p];
+        float2* t = a; a = b; b = t;
+    }
+    __syncthreads();
+    return a;
+}
+
+template <int F>
+struct Cfg {
+    static constexpr int M = F / 2;
+    static constexpr int T = (M / 8) < 16 ? 16 : (M / 8);   // lanes per frame
+    static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
+    static constexpr int FPW = WG / T;                      // frames per workgroup iteration
+    // LDS: twM[M] + twF[M+1] (float2), window[F] (float), 2 buffers of M float2 per frame
+    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * 2 * M * 8;
+};
+
+template <int F>
+__device__ __forceinline__ void build_tables(float2* twM, float2* twF, float* win, int frame_length) {
+    constexpr int M = F / 2;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)M, &s, &c);
+        twM[k] = make_float2((float)c, (float)s);
+    }
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)F, &s, &c);
+        twF[k] = make_float2((float)c, (float)s);
+    }
+    if (win) {
+        // periodic Hann of `frame_length`, centre-padded to F (data.py:627-629)
+        const int lpad = (F - frame_length) / 2;
+        for (int n = threadIdx.x; n < F; n += blockDim.x) {
+            int q = n - lpad;
+            double w = 0.0;
+            if (q >= 0 && q < frame_length) w = 0.5 - 0.5 * cospi(2.0 * (double)q / (double)frame_length);
+            win[n] = (float)w;
+        }
+    }
+}
+
+// X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
+template <int M>
+__device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, int k) {
+    float2 zk = Z[k & (M - 1)];
+    float2 zm = Z[(M - k) & (M - 1)];
+    zm.y = -zm.y;
+    float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+    float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
+    float2 t = cmul(twF[k], o);
+    return cadd(e, mul_mi(t));
+}
+
+// ---- dense power spectra --------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
+                                                            int C, int hop, int64_t H, int64_t total_frames,
+                                                            float* __restrict__ power) {
+    using G = Cfg<F>;
+    constexpr int M = G::M, T = G::T, FPW = G::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* twM = reinterpret_cast<float2*>(smem);
+    float2* twF = twM + M;
+    float* win = reinterpret_cast<float*>(twF + M + 2);
+    float2* bufs = reinterpret_cast<float2*>(win + F);
+    build_tables<F>(twM, twF, win, F);
+    const int sub = threadIdx.x / T;  // frame slot within the workgroup
+    const int tid = threadIdx.x % T;
+    float2* A = bufs + (size_t)sub * 2 * M;
+    float2* Bf = A + M;
+    const int64_t n_groups = cdiv(total_frames, FPW);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
+        const bool valid = f < total_frames;
+        __syncthreads();  // tables ready / previous iteration's reads done
+        if (valid) {
+            const int64_t h = f % H;
+            const int64_t cc = f / H;  // clip*C + c
+            const int c = (int)(cc % C);
+            const int64_t clip = cc / C;
+            const float* src = x + (clip * n_samples + h * hop) * C + c;
+            for (int n = tid; n < M; n += T) {
+                float a = src[(int64_t)(2 * n) * C] * win[2 * n];
+                float b = src[(int64_t)(2 * n + 1) * C] * win[2 * n + 1];
+                A[n] = make_float2(a, b);
+            }
+        }
+        float2* Z = cfft<M, T>(A, Bf, twM, tid);
+        if (valid) {
+            float* dst = power + f * (M + 1);
+            for (int k = tid; k <= M; k += T) {
+                float2 X = rfft_bin<M>(Z, twF, k);
+                dst[k] = X.x * X.x + X.y * X.y;
+            }
+        }
+    }
+}
+
+// ---- gathered complex frames (data.stft) ------------------------------------
+struct FrameArgs {
+    const float* x;
+    int64_t n_samples;
+    int C;
+    const int32_t* clip;
+    const int32_t* channel;
+    const int64_t* start;
+    const int64_t* valid_lo;
+    const int64_t* valid_hi;
+    int64_t n_frames;
+    int frame_length;
+    const float* window;  // [F]
+    float2* spec;         // [n_frames][F/2+1]
+};
+
+template <int F>
+__global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
+    using G = Cfg<F>;
+    constexpr int M = G::M, T = G::T, FPW = G::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* twM = reinterpret_cast<float2*>(smem);
+    float2* twF = twM + M;
+    float* win = reinterpret_cast<float*>(twF + M + 2);
+    float2* bufs = reinterpret_cast<float2*>(win + F);
+    build_tables<F>(twM, twF, nullptr, F);
+    for (int n = threadIdx.x; n < F; n += blockDim.x) win[n] = a.window[n];
+    const int sub = threadIdx.x / T;
+    const int tid = threadIdx.x % T;
+    float2* A = bufs + (size_t)sub * 2 * M;
+    float2* Bf = A + M;
+    const int lpad = (F - a.frame_length) / 2;  // librosa.util.pad_center (data.py:588-589)
+    const int64_t n_groups = cdiv(a.n_frames, FPW);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t f = grp * FPW + sub;
+        const bool valid = f < a.n_frames;
+        __syncthreads();
+        if (valid) {
+            const int64_t st = a.start[f], lo = a.valid_lo[f], hi = a.valid_hi[f];
+            const float* src = a.x + ((int64_t)a.clip[f] * a.n_samples) * a.C + a.channel[f];
+            for (int n = tid; n < M; n += T) {
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int p = 2 * n + e;
+                    int q = p - lpad;
+                    int64_t idx = st + q;
+                    float s = 0.0f;
+                    if (q >= 0 && q < a.frame_length && idx >= lo && idx < hi && idx >= 0 && idx < a.n_samples)
+                        s = src[idx * a.C];
+                    v[e] = s * win[p];
+                }
+                A[n] = make_float2(v[0], v[1]);
+            }
+        }
+        float2* Z = cfft<M, T>(A, Bf, twM, tid);
+        if (valid) {
+            float2* dst = a.spec + f * (M + 1);
+            for (int k = tid; k <= M; k += T) dst[k] = rfft_bin<M>(Z, twF, k);
+        }
+    }
+}
+
+// ---- FrameExtractor gather (data.py:90-120) -----------------------------------
+__global__ __launch_bounds__(256) void k_extract(const float* __restrict__ x, int64_t n_samples, int C,
+                                                 const int64_t* __restrict__ start, int64_t n_onsets, int width,
+                                                 float* __restrict__ out) {
+    const int64_t total = n_onsets * C * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int w = (int)(i % width);
+        int64_t oc = i / width;
+        int c = (int)(oc % C);
+        int64_t t = start[oc] + w;
+        out[i] = (t >= 0 && t < n_samples) ? x[t * C + c] : 0.0f;
+    }
+}
+
+// ---- mel: sparse triangular filterbank, one thread per (row, band) ------------
+__global__ __launch_bounds__(256) void k_mel(const float* __restrict__ power, int64_t n_rows, int n_bins,
+                                             int n_mels, const int32_t* __restrict__ lo,
+                                             const int32_t* __restrict__ len, const int32_t* __restrict__ off,
+                                             const float* __restrict__ w, float* __restrict__ mel) {
+    const int64_t total = n_rows * n_mels;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int b = (int)(i % n_mels);
+        int64_t r = i / n_mels;
+        const float* p = power + r * n_bins + lo[b];
+        const float* wb = w + off[b];
+        float acc = 0.0f;
+        for (int k = 0; k < len[b]; ++k) acc = fmaf(p[k], wb[k], acc);
+        mel[i] = acc;
+    }
+}
+
+// ---- power_to_db + DCT (data.py:677-679) ---------------------------------------
+__global__ __launch_bounds__(256) void k_max(const float* __restrict__ v, int64_t n, float* out) {
+    float m = 0.0f;  // inputs are non-negative powers
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int64_t n_rows, int n_mels,
+                                              int n_mfcc, float amin, float top_db,
+                                              const float* __restrict__ dct, const float* __restrict__ gmax,
+                                              float* __restrict__ out) {
+    const int64_t total = n_rows * n_mfcc;
+    float lo = -INFINITY;
+    if (top_db >= 0.0f) lo = 10.0f * log10f(fmaxf(amin, *gmax)) - top_db;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int q = (int)(i % n_mfcc);
+        int64_t r = i / n_mfcc;
+        const float* m = mel + r * n_mels;
+        const float* d = dct + (int64_t)q * n_mels;
+        float acc = 0.0f;
+        for (int b = 0; b < n_mels; ++b) {
+            float db = fmaxf(10.0f * log10f(fmaxf(amin, m[b])), lo);
+            acc = fmaf(db, d[b], acc);
+        }
+        out[i] = acc;
+    }
+}
+
+template <int F>
+int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
+                 hipStream_t stream) {
+    using G = Cfg<F>;
+    static bool attr_set = false;
+    if (!attr_set && G::lds_bytes > 65536) {
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
+        attr_set = true;
+    }
+    int64_t groups = cdiv(total, G::FPW);
+    unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
+    hipLaunchKernelGGL(k_stft_power<F>, dim3(grid), dim3(G::WG), G::lds_bytes, stream, x, n_samples, C, hop, H,
+                       total, power);
+    OFP_LAUNCH_CHECK("k_stft_power");
+    return OFP_OK;
+}
+
+template <int F>
+int launch_frames(const FrameArgs& a, hipStream_t stream) {
+    using G = Cfg<F>;
+    static bool attr_set = false;
+    if (!attr_set && G::lds_bytes > 65536) {
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_frames<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
+        attr_set = true;
+    }
+    int64_t groups = cdiv(a.n_frames, G::FPW);
+    unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
+    hipLaunchKernelGGL(k_stft_frames<F>, dim3(grid), dim3(G::WG), G::lds_bytes, stream, a);
+    OFP_LAUNCH_CHECK("k_stft_frames");
+    return OFP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
+                   int32_t hop, float* d_power, void* stream_) {
+    OFP_REQUIRE(d_x && d_power, "ofp_stft_power: NULL argument");
+    OFP_REQUIRE(n_clips >= 1 && C >= 1 && hop >= 1, "ofp_stft_power: bad sizes");
+    if (n_samples < n_fft) return OFP_OK;  // no complete frame
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t H = 1 + (n_samples - n_fft) / hop;
+    const int64_t total = n_clips * C * H;
+    switch (n_fft) {
+        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        default: return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", n_fft);
+    }
+}
+
+int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, const int32_t* d_clip,
+                    const int32_t* d_channel, const int64_t* d_start, const int64_t* d_valid_lo,
+                    const int64_t* d_valid_hi, int64_t n_frames, int32_t frame_length, int32_t n_fft,
+                    const float* d_window, float* d_spec, void* stream_) {
+    if (n_frames == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_clip && d_channel && d_start && d_valid_lo && d_valid_hi && d_window && d_spec,
+                "ofp_stft_frames: NULL argument");
+    OFP_REQUIRE(frame_length >= 1 && frame_length <= n_fft, "frame_length %d must be in [1, n_fft]", frame_length);
+    (void)n_clips;
+    FrameArgs a;
+    a.x = d_x; a.n_samples = n_samples; a.C = C; a.clip = d_clip; a.channel = d_channel; a.start = d_start;
+    a.valid_lo = d_valid_lo; a.valid_hi = d_valid_hi; a.n_frames = n_frames; a.frame_length = frame_length;
+    a.window = d_window; a.spec = reinterpret_cast<float2*>(d_spec);
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (n_fft) {
+        case 256: return launch_frames<256>(a, stream);
+        case 512: return launch_frames<512>(a, stream);
+        case 1024: return launch_frames<1024>(a, stream);
+        case 2048: return launch_frames<2048>(a, stream);
+        case 4096: return launch_frames<4096>(a, stream);
+        default: return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", n_fft);
+    }
+}
+
+int ofp_extract_frames(const float* d_x, int64_t n_samples, int32_t C, const int64_t* d_start,
+                       int64_t n_onsets, int32_t width, float* d_out, void* stream) {
+    if (n_onsets == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_start && d_out && width >= 1 && C >= 1, "ofp_extract_frames: bad argument");
+    int64_t total = n_onsets * C * width;
+    unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_extract, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n_samples, C, d_start,
+                       n_onsets, width, d_out);
+    OFP_LAUNCH_CHECK("k_extract");
+    return OFP_OK;
+}
+
+int ofp_mel(const float* d_power, int64_t n_rows, int32_t n_bins, int32_t n_mels, const int32_t* d_fb_lo,
+            const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, float* d_mel, void* stream) {
+    if (n_rows == 0) return OFP_OK;
+    OFP_REQUIRE(d_power && d_fb_lo && d_fb_len && d_fb_off && d_fb_w && d_mel, "ofp_mel: NULL argument");
+    int64_t total = n_rows * n_mels;
+    unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_mel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_power, n_rows, n_bins, n_mels,
+                       d_fb_lo, d_fb_len, d_fb_off, d_fb_w, d_mel);
+    OFP_LAUNCH_CHECK("k_mel");
+    return OFP_OK;
+}
+
+int ofp_mfcc(const float* d_mel, int64_t n_rows, int32_t n_mels, int32_t n_mfcc, float amin, float top_db,
+             const float* d_dct, float* d_mfcc, float* d_scratch, void* stream_) {
+    if (n_rows == 0) return OFP_OK;
+    OFP_REQUIRE(d_mel && d_dct && d_mfcc && d_scratch, "ofp_mfcc: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    OFP_HIP(hipMemsetAsync(d_scratch, 0, 4, stream));
+    int64_t n = n_rows * n_mels;
+    if (top_db >= 0.0f) {
+        unsigned g1 = (unsigned)std::min<int64_t>(cdiv(n, 256), 1024);
+        hipLaunchKernelGGL(k_max, dim3(g1), dim3(256), 0, stream, d_mel, n, d_scratch);
+        OFP_LAUNCH_CHECK("k_max");
+    }
+    int64_t total = n_rows * n_mfcc;
+    unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(256), 0, stream, d_mel, n_rows, n_mels, n_mfcc, amin, top_db,
+                       d_dct, (const float*)d_scratch, d_mfcc);
+    OFP_LAUNCH_CHECK("k_mfcc");
+    return OFP_OK;
+}
+
+}  // extern "C"

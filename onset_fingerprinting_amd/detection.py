@@ -1,0 +1,293 @@
+"""Onset detection on MI355X -- drop-in surface of the reference's
+``onset_fingerprinting/detection.py`` for the amplitude detector.
+
+Same names, arguments, defaults, return shapes and dtypes as the reference
+(detection.py:12-86, :487-888); the work is done by hand-written HIP kernels in
+``libonsetfp.so`` (csrc/ofp_detect.hip, ofp_stream.hip) through ctypes.  There is
+no CPU path: without the library or a gfx950 GPU every call raises.
+
+Additional, batched entry points (`BatchDetector`, `detect_batch`) keep audio,
+relative envelope and onset records resident in HBM.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from scipy import signal as sig
+
+from . import _lib
+from ._lib import DetectorParams, DetectTuning, OnsetFPError, check
+
+ONSET_DTYPE = np.dtype([("clip", np.int32), ("channel", np.int32), ("sample", np.int64)])
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev(device):
+    if isinstance(device, torch.device):
+        return device
+    return torch.device("cuda", int(device))
+
+
+class _DeviceDetector:
+    """Owns the opaque ofp_detector handle built from the reference's kwargs."""
+
+    def __init__(self, n_signals, block_size, floor, hipass_freq, fast_ar, slow_ar, on_threshold,
+                 off_threshold, cooldown, backtrack, backtrack_buffer_size, backtrack_smooth_size, sr,
+                 device=0):
+        self.lib = _lib.lib()
+        _lib.require_gpu(_dev(device).index or 0)
+        self.device = _dev(device)
+        torch.cuda.set_device(self.device)
+        p = DetectorParams()
+        p.n_channels = int(n_signals)
+        p.block_size = int(block_size)
+        p.floor_db = floor
+        p.hp_enabled = int(hipass_freq != 0)
+        if p.hp_enabled:
+            # detection.py:492-496: scipy design in double, coefficients cast to float32
+            b, a = sig.butter(4, hipass_freq, btype="high", analog=False, output="ba", fs=sr)
+            p.hp_b[:] = [float(v) for v in np.float32(b)]
+            p.hp_a[:] = [float(v) for v in np.float32(a)]
+        # detection.py:514-515: the follower coefficients are np.float32(1 / x)
+        p.fast_attack, p.fast_release = np.float32(1 / fast_ar[0]), np.float32(1 / fast_ar[1])
+        p.slow_attack, p.slow_release = np.float32(1 / slow_ar[0]), np.float32(1 / slow_ar[1])
+        # detection.py:703-708
+        p.alpha_min, p.alpha_max, p.minmin = 1e-4, 1e-5, 2.0
+        p.min0, p.max0 = 0.0, 10.0
+        on = np.ascontiguousarray(np.broadcast_to(np.asarray(on_threshold, dtype=np.float64), (n_signals,)))
+        off = np.ascontiguousarray(np.broadcast_to(np.asarray(off_threshold, dtype=np.float64), (n_signals,)))
+        p.manual = int(bool(np.all(np.asarray(on_threshold) > 1)))  # detection.py:687
+        p.cooldown = int(cooldown)
+        p.backtrack = int(bool(backtrack))
+        p.backtrack_buffer_size = int(backtrack_buffer_size)
+        if backtrack:
+            assert block_size <= backtrack_buffer_size, \
+                "backtrack_buffer_size should be at least block_size!"  # detection.py:716-718
+            b_alpha = np.float32(2 / (backtrack_smooth_size + 1))
+            p.backtrack_alpha = b_alpha
+            p.backtrack_tol = np.float32((1 - b_alpha) ** backtrack_buffer_size)
+        self.params = p
+        self._on, self._off = on, off
+        h = ctypes.c_void_p()
+        check(self.lib.ofp_detector_create(ctypes.byref(p), on.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                           off.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                           ctypes.byref(h)), "ofp_detector_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ofp_detector_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tuning(self, **kw):
+        t = DetectTuning()
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        check(self.lib.ofp_detector_set_tuning(self.handle, ctypes.byref(t)), "ofp_detector_set_tuning")
+
+
+class BatchDetector:
+    """Offline detection of a batch of independent clips, resident in HBM.
+
+    One instance == the reference's ``detect_onsets_amplitude`` configuration
+    (detection.py:19-86) applied to every clip of ``x [n_clips, N, C]``.
+    """
+
+    def __init__(self, n_signals, block_size=128, floor=-70.0, hipass_freq=2000.0,
+                 fast_ar=(3.0, 383.0), slow_ar=(2205.0, 2205.0), on_threshold=0.5, off_threshold=0.1,
+                 cooldown=1323, backtrack=False, backtrack_buffer_size=128, backtrack_smooth_size=5,
+                 sr=96000, device=0):
+        self.d = _DeviceDetector(n_signals, block_size, floor, hipass_freq, fast_ar, slow_ar, on_threshold,
+                                 off_threshold, cooldown, backtrack, backtrack_buffer_size,
+                                 backtrack_smooth_size, sr, device)
+        self.n_signals, self.block_size, self.sr = n_signals, block_size, sr
+        self.device = self.d.device
+        self._ws = None
+        self.last_info = None
+
+    def set_tuning(self, **kw):
+        self.d.set_tuning(**kw)
+
+    def workspace_bytes(self, n_clips, n_samples, warm):
+        return int(self.d.lib.ofp_detect_workspace_bytes(self.d.handle, n_clips, n_samples, warm))
+
+    def reserve(self, n_clips, n_samples, warm):
+        need = self.workspace_bytes(n_clips, n_samples, warm)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None):
+        """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of
+        device tensors: ``records`` (uint8 view of ofp_onset [n_clips, cap]),
+        ``counts`` int64 [n_clips], ``rel`` float32 [n_clips, N', C] or None."""
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n_clips, N, C = x.shape
+        assert C == self.n_signals
+        B = self.block_size
+        warm = int(0.5 * self.sr) if warm is None else int(warm)
+        nb = N // B
+        cap = int(cap_per_clip) if cap_per_clip is not None else max(1, min(nb * C, 1 << 16))
+        ws = self.reserve(n_clips, N, warm)
+        if out is None:
+            out = {
+                "records": torch.empty((n_clips, cap, 16), dtype=torch.uint8, device=x.device),
+                "counts": torch.zeros(n_clips, dtype=torch.int64, device=x.device),
+                "rel": torch.empty((n_clips, nb * B, C), dtype=torch.float32, device=x.device) if want_rel else None,
+            }
+        info = (ctypes.c_int64 * 4)()
+        rel = out["rel"]
+        check(self.d.lib.ofp_detect_offline(
+            self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
+            out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
+            _stream_ptr(x.device)), "ofp_detect_offline")
+        self.last_info = dict(hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3])
+        out["cap"] = cap
+        return out
+
+    @staticmethod
+    def records_to_numpy(out):
+        """-> list (one per clip) of structured arrays (clip, channel, sample), in the
+        reference's order (block, then channel)."""
+        counts = out["counts"].cpu().numpy()
+        cap = out["cap"]
+        if counts.max(initial=0) > cap:
+            raise OnsetFPError(f"{counts.max()} onsets in a clip exceed the record capacity {cap}")
+        recs = out["records"].cpu().numpy().view(ONSET_DTYPE).reshape(len(counts), cap)
+        return [recs[i, :counts[i]].copy() for i in range(len(counts))]
+
+
+def detect_batch(x, block_size=128, sr=96000, device=0, warm=None, want_rel=True, tuning=None, **kw):
+    """Convenience: numpy/tensor [n_clips, N, C] -> (list of record arrays, rel numpy or None)."""
+    xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x
+    xt = xt.to(_dev(device))
+    if xt.dim() == 2:
+        xt = xt.unsqueeze(0)
+    bd = BatchDetector(xt.shape[-1], block_size, sr=sr, device=device, **kw)
+    if tuning:
+        bd.set_tuning(**tuning)
+    out = bd.detect(xt.contiguous(), warm=warm, want_rel=want_rel)
+    recs = BatchDetector.records_to_numpy(out)
+    rel = out["rel"].cpu().numpy() if want_rel else None
+    return recs, rel, bd.last_info
+
+
+def detect_onsets(x: np.ndarray, sr: int = 96000, method="amp"):
+    """detection.py:12-16."""
+    if method == "amp":
+        return detect_onsets_amplitude(x, sr=sr)
+    raise NotImplementedError("detect_onsets_spectral is outside the accelerated hot path (SURVEY.md 8f N1)")
+
+
+def detect_onsets_amplitude(
+    x: np.ndarray,
+    block_size: int = 128,
+    floor: float = -70.0,
+    hipass_freq: float = 2000.0,
+    fast_ar: tuple = (3.0, 383.0),
+    slow_ar: tuple = (2205.0, 2205.0),
+    on_threshold=0.5,
+    off_threshold=0.1,
+    cooldown: int = 1323,
+    backtrack: bool = False,
+    backtrack_buffer_size: int = 128,
+    backtrack_smooth_size: int = 5,
+    sr: int = 96000,
+    device=0,
+):
+    """Detects onsets using amplitude followers (detection.py:19-86): x is NxC
+    float32; returns ``(channels_flat, onsets_flat, rel)`` with ``rel`` of shape
+    ``[floor(N/block_size)*block_size, C]``."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    recs, rel, _ = detect_batch(
+        x[None], block_size=block_size, sr=sr, device=device, floor=floor, hipass_freq=hipass_freq,
+        fast_ar=fast_ar, slow_ar=slow_ar, on_threshold=on_threshold, off_threshold=off_threshold,
+        cooldown=cooldown, backtrack=backtrack, backtrack_buffer_size=backtrack_buffer_size,
+        backtrack_smooth_size=backtrack_smooth_size)
+    r = recs[0]
+    return [np.int64(c) for c in r["channel"]], [np.int64(s) for s in r["sample"]], rel[0]
+
+
+class AmplitudeOnsetDetector:
+    """Multi-channel amplitude/time-domain onset detector (detection.py:595-888),
+    streaming form: the detector state lives in HBM and each ``__call__`` is one
+    kernel launch (csrc/ofp_stream.hip)."""
+
+    def __init__(self, n_signals: int, block_size: int = 32, floor: float = -70.0,
+                 hipass_freq: float = 2000.0, fast_ar=(3.0, 383.0), slow_ar=(2205.0, 2205.0),
+                 on_threshold: float = 0.5, off_threshold: float = 0.1, cooldown: int = 1323,
+                 backtrack: bool = False, backtrack_buffer_size: int = 80,
+                 backtrack_smooth_size: int = 5, sr: int = 44100, device=0):
+        self.n_signals = n_signals
+        self.block_size = block_size
+        self.floor = floor
+        self.on_threshold = on_threshold
+        self.manual = True if np.all(np.asarray(on_threshold) > 1) else False
+        self.off_threshold = off_threshold
+        self.cooldown = cooldown
+        self.sr = sr
+        self.backtrack = backtrack
+        self.d = _DeviceDetector(n_signals, block_size, floor, hipass_freq, fast_ar, slow_ar, on_threshold,
+                                 off_threshold, cooldown, backtrack, backtrack_buffer_size,
+                                 backtrack_smooth_size, sr, device)
+        dev = self.d.device
+        nbytes = int(self.d.lib.ofp_stream_state_bytes(self.d.handle))
+        self._state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        check(self.d.lib.ofp_stream_state_init(self.d.handle, self._state.data_ptr(), _stream_ptr(dev)),
+              "ofp_stream_state_init")
+        self._xbuf = torch.empty((block_size, n_signals), dtype=torch.float32, device=dev)
+        self._rel = torch.empty((block_size, n_signals), dtype=torch.float32, device=dev)
+        self._rec = torch.empty((max(1, n_signals), 16), dtype=torch.uint8, device=dev)
+        self._cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _check_block(self, x):
+        x = np.ascontiguousarray(x)
+        if x.dtype != np.float32:
+            # the reference's ctypes ndpointer rejects non-float32 input (detection.py:521-526)
+            raise ctypes.ArgumentError(f"array must have data type float32, got {x.dtype}")
+        return x
+
+    def process(self, x_dev, n_blocks, sample_base=0, rel=None, records=None, count=None):
+        """Device-resident form: x_dev float32 CUDA [n_blocks*B, C]; appends to
+        `records`/`count` (device).  No host synchronisation."""
+        cap = records.shape[0] if records is not None else 0
+        check(self.d.lib.ofp_stream_process(
+            self.d.handle, self._state.data_ptr(), x_dev.data_ptr(), n_blocks, 0, 0, sample_base,
+            rel.data_ptr() if rel is not None else None,
+            records.data_ptr() if records is not None else None, cap,
+            count.data_ptr() if count is not None else None, _stream_ptr(x_dev.device)), "ofp_stream_process")
+
+    def __call__(self, x: np.ndarray):
+        """x: [block_size, n_signals] float32 -> (channels, deltas, relative_envelope)
+        (detection.py:727-798)."""
+        x = self._check_block(x)
+        if x.shape != (self.block_size, self.n_signals):
+            raise ValueError(f"expected block of shape {(self.block_size, self.n_signals)}, got {x.shape}")
+        self._xbuf.copy_(torch.from_numpy(x))
+        self._cnt.zero_()
+        self.process(self._xbuf, 1, 0, self._rel, self._rec, self._cnt)
+        k = int(self._cnt.item())
+        recs = self._rec.cpu().numpy().view(ONSET_DTYPE).reshape(-1)[:k]
+        return recs["channel"].astype(np.int64), recs["sample"].astype(np.int64), self._rel.cpu().numpy()
+
+    def init_minmax_tracker(self, x):
+        """detection.py:827-840."""
+        x = self._check_block(x)
+        if len(x) == 0:
+            return
+        xd = torch.from_numpy(x).to(self.d.device)
+        check(self.d.lib.ofp_stream_process(
+            self.d.handle, self._state.data_ptr(), xd.data_ptr(), 0, x.shape[0], 1, 0, None, None, 0, None,
+            _stream_ptr(xd.device)), "ofp_stream_process(warmup)")
+        torch.cuda.current_stream(xd.device).synchronize()

@@ -84,6 +84,37 @@ void oracle_backtrack_onsets(const float* buffer, const long* channels, long* de
     }
 }
 
+/* ---- detection.py:800-825: the Python backtracking that AmplitudeOnsetDetector
+ * actually runs.  Same arithmetic as the C function above, but `i` is advanced
+ * BEFORE the loop (detection.py:813), so the walk stops one row earlier than
+ * envelope_follower.c:73-76 allows.  `buffer` is the last N rows of the relative
+ * envelope, oldest first (detection.py:802-803).  The C variant is pinned by
+ * golden set g9; this variant cannot be run from the reference here (its ring
+ * buffer class comes from the absent `loopmate` package) and is pinned only
+ * through the shared arithmetic: PARITY UNPINNED for the loop bound. */
+void oracle_backtrack_onsets_py(const float* buffer, const long* channels, long* deltas,
+                                float alpha, float tol, long buffer_length,
+                                long n_onsets, long n_channels, long block_size) {
+    float omba = (float)(1.0 - (double)alpha); /* np.float32(1 - self.b_alpha) */
+    long N = buffer_length;
+    for (long j = 0; j < n_onsets; j++) {
+        long channel = channels[j];
+        long i = block_size - deltas[j];
+        float current_smoothed = buffer[(N - i) * n_channels + channel];
+        i += 1;
+        float prev = (N - i) >= 0 ? buffer[(N - i) * n_channels + channel] : 0.0f;
+        float prev_smoothed = alpha * prev + omba * current_smoothed;
+        while ((current_smoothed > prev_smoothed) &&
+               (fabsf(prev_smoothed - prev) > tol) && (i + 1 < N)) {
+            deltas[j] -= 1;
+            i += 1;
+            current_smoothed = prev_smoothed;
+            prev = buffer[(N - i) * n_channels + channel];
+            prev_smoothed = alpha * prev + omba * current_smoothed;
+        }
+    }
+}
+
 /* ---- detection.py:487-501: scipy.signal.lfilter(b, a, x, axis=0, zi) in
  * float32, order 4; zi is [4][C]; x,y are [n][C].  b,a are normalised by a[0]
  * in fp32 first, as scipy's C kernel does. */
@@ -294,8 +325,8 @@ long oracle_detector_block(oracle_detector* d, const float* x, float* rel,
     for (int c = 0; c < C; ++c)                                     /* :795 */
         if (onflag[c]) { channels[k] = c; deltas[k] = on_idx[c]; ++k; }
     if (p->backtrack && k > 0)                                      /* :796-797 */
-        oracle_backtrack_onsets(d->hist, channels, deltas, p->bt_alpha, p->bt_tol,
-                                p->bt_N, k, C, B);
+        oracle_backtrack_onsets_py(d->hist, channels, deltas, p->bt_alpha, p->bt_tol,
+                                   p->bt_N, k, C, B);
     return k;
 }
 

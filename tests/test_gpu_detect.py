@@ -1,0 +1,199 @@
+"""GPU parity of the HIP onset detector against the CPU oracle (and through it
+against the reference's golden vectors).  Every call goes through the C ABI of
+libonsetfp.so.  Integer outputs must match exactly; the relative envelope must
+match bit-for-bit because both sides evaluate include/ofp_math.h."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from onset_fingerprinting_amd import synth
+from tests.conftest import load_golden
+from tests.golden.make_golden_cfg import G3_CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000
+
+
+@pytest.fixture(scope="module")
+def det():
+    from onset_fingerprinting_amd import detection
+    return detection
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def oracle_records(x, **kw):
+    c, o, rel = oracle.detect_onsets_amplitude(x, **kw)
+    return np.array(c, np.int64), np.array(o, np.int64), rel
+
+
+def check_clip(det, x, tuning=None, **kw):
+    recs, rel, info = det.detect_batch(x[None], tuning=tuning, **kw)
+    c, o, orel = oracle_records(x, **kw)
+    assert np.array_equal(recs[0]["channel"], c), (recs[0]["channel"][:20], c[:20])
+    assert np.array_equal(recs[0]["sample"], o)
+    assert rel[0].shape == orel.shape
+    assert np.array_equal(bits(rel[0]), bits(orel)), "relative envelope not bit-identical"
+    return info, len(c)
+
+
+def test_c1_offline_matches_oracle_and_golden(det):
+    x = synth.c1_sine_clicks(10.0, SR, seed=0)
+    g = load_golden("g4_end_to_end")
+    for B in (128, 256):
+        c, o, rel = det.detect_onsets_amplitude(x, block_size=B, sr=SR)
+        # the reference's own answer (captured in tests/golden)
+        assert np.array_equal(np.array(c), g[f"c1_B{B}_ch"])
+        assert np.array_equal(np.array(o), g[f"c1_B{B}_on"])
+        oc, oo, orel = oracle_records(x, block_size=B, sr=SR)
+        assert np.array_equal(bits(rel), bits(orel))
+        assert isinstance(c, list) and rel.dtype == np.float32 and rel.shape == (480000 // B * B, 1)
+
+
+def test_c2_slice_default_tuning(det):
+    x = synth.c2_drums(10.0, 8, SR, seed=1)
+    g = load_golden("g4_end_to_end")
+    info, n = check_clip(det, x, block_size=256, sr=SR)
+    assert n == len(g["c2_ch"]) and n > 100
+    c, o, _ = det.detect_onsets_amplitude(x, block_size=256, sr=SR)
+    assert np.array_equal(np.array(c), g["c2_ch"]) and np.array_equal(np.array(o), g["c2_on"])
+
+
+@pytest.mark.parametrize("tuning", [
+    dict(hp_chunk=1024, hp_warm=2048, ar_chunk=2048, ar_warm=60000, mm_chunk=4096, mm_warm=50000),
+    # no speculative warm-up at all: every chunk starts wrong, the repair passes must fix it
+    dict(hp_chunk=20000, hp_warm=-1, ar_chunk=30000, ar_warm=-1, mm_chunk=25000, mm_warm=-1),
+    dict(hp_chunk=777, hp_warm=100, ar_chunk=5000, ar_warm=1000, mm_chunk=999, mm_warm=10),
+])
+def test_time_parallel_passes_are_exact(det, tuning):
+    x = synth.c2_drums(3.0, 4, SR, seed=5)
+    info, n = check_clip(det, x, tuning=tuning, block_size=256, sr=SR)
+    assert n > 10
+    if tuning["hp_warm"] == -1:
+        assert info["repaired"] > 0  # the fallback path really ran
+
+
+@pytest.mark.parametrize("kw", [
+    dict(block_size=128, hipass_freq=0, on_threshold=6.0, off_threshold=4.0, cooldown=20),
+    dict(block_size=32, hipass_freq=1000.0, on_threshold=0.2, off_threshold=0.15, cooldown=0, fast_ar=(2.0, 966.0)),
+    dict(block_size=512, hipass_freq=2000.0, on_threshold=6.1, off_threshold=2.3, cooldown=300, floor=-60.0),
+    dict(block_size=128, hipass_freq=0, fast_ar=(0.3, 800.0), slow_ar=(8000.0, 8000.0), on_threshold=0.45,
+         off_threshold=0.45, cooldown=9600),
+    dict(block_size=64, backtrack=True, backtrack_buffer_size=128, backtrack_smooth_size=5),
+    dict(block_size=128, backtrack=True, backtrack_buffer_size=128, backtrack_smooth_size=3, on_threshold=6.0,
+         off_threshold=4.0),
+])
+def test_parameter_sets(det, kw):
+    x = synth.drum_hits(3, 2.0, SR, seed=21, period=0.23)
+    check_clip(det, x, sr=SR, **kw)
+
+
+def test_batch_of_ragged_and_edge_cases(det):
+    # several clips at once; a clip shorter than the warm-up; N not a multiple of B
+    xs = np.stack([synth.c4_clip(i, 1.3, 4, SR) for i in range(5)])[:, :61234]
+    recs, rel, _ = det.detect_batch(xs, block_size=256, sr=SR)
+    for i in range(5):
+        c, o, orel = oracle_records(xs[i], block_size=256, sr=SR)
+        assert np.array_equal(recs[i]["channel"], c) and np.array_equal(recs[i]["sample"], o)
+        assert np.array_equal(recs[i]["clip"], np.full(len(c), i, np.int32))
+        assert np.array_equal(bits(rel[i]), bits(orel))
+    # shorter than one block: nothing processed (detection.py:74-75)
+    x = synth.c4_clip(0, 1.0, 2, SR)[:100]
+    c, o, r = det.detect_onsets_amplitude(x, block_size=128, sr=SR)
+    assert c == [] and o == [] and r.shape == (0, 2)
+    # shorter than the warm-up window
+    x = synth.drum_hits(2, 0.3, SR, seed=3, period=0.1)
+    check_clip(det, x, block_size=128, sr=SR)
+
+
+@pytest.mark.parametrize("k", range(len(G3_CONFIGS)))
+def test_streaming_detector_blocks_match_golden_and_oracle(det, k):
+    g = load_golden("g3_detector_blocks")
+    for tag, x in (("a", g["x"]), ("b", g["x2"])):
+        cfg = dict(G3_CONFIGS[k])
+        B = cfg.pop("block_size")
+        od = det.AmplitudeOnsetDetector(x.shape[1], B, sr=SR, **cfg)
+        oo = oracle.OracleDetector(x.shape[1], B, sr=SR, **cfg)
+        if k % 2 == 1:
+            od.init_minmax_tracker(x[: int(0.05 * SR)])
+            oo.init_minmax_tracker(x[: int(0.05 * SR)])
+        recs = []
+        for i in range(0, len(x) - B + 1, B):
+            c, d, r = od(x[i:i + B])
+            c2, d2, r2 = oo(x[i:i + B])
+            assert np.array_equal(c, c2) and np.array_equal(d, d2), (i, c, c2, d, d2)
+            assert np.array_equal(bits(r), bits(r2))
+            recs += [(i // B, int(a), int(b)) for a, b in zip(c, d)]
+        assert np.array_equal(np.array(recs, np.int64).reshape(-1, 3), g[f"rec_{k}{tag}"])
+
+
+def test_streaming_multi_block_call_and_backtrack(det):
+    import torch
+    x = synth.drum_hits(4, 1.0, SR, seed=31, period=0.17)
+    B = 64
+    kw = dict(backtrack=True, backtrack_buffer_size=128, backtrack_smooth_size=5, cooldown=500)
+    od = det.AmplitudeOnsetDetector(4, B, sr=SR, **kw)
+    oo = oracle.OracleDetector(4, B, sr=SR, **kw)
+    nb = len(x) // B
+    xd = torch.from_numpy(x[: nb * B]).cuda()
+    rel = torch.empty_like(xd)
+    rec = torch.empty((4096, 16), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    od.process(xd, nb, 0, rel, rec, cnt)
+    n = int(cnt.item())
+    got = rec.cpu().numpy().view(det.ONSET_DTYPE).reshape(-1)[:n]
+    exp = []
+    rels = []
+    for i in range(nb):
+        c, d, r = oo(x[i * B:(i + 1) * B])
+        rels.append(r)
+        exp += [(int(a), i * B + int(b)) for a, b in zip(c, d)]
+    assert n == len(exp) and n > 5
+    assert [(int(a), int(b)) for a, b in zip(got["channel"], got["sample"])] == exp
+    assert np.array_equal(bits(rel.cpu().numpy()), bits(np.concatenate(rels)))
+
+
+def test_legacy_symbols_match_oracle(det):
+    from onset_fingerprinting_amd import _lib
+    L = _lib.lib()
+    g = load_golden("g1_ar_envelope")
+    x = g["x"]
+    B, C = 64, x.shape[1]
+    fp = ctypes.POINTER(ctypes.c_float)
+    for k, (a, r) in enumerate(g["pairs"]):
+        y = np.full((B, C), -70.0, np.float32)
+        outs = []
+        for i in range(0, len(x), B):
+            xb = np.ascontiguousarray(x[i:i + B])
+            L.ar_envelope(xb.ctypes.data_as(fp), y.ctypes.data_as(fp), np.float32(1 / a), np.float32(1 / r), C, B)
+            outs.append(y.copy())
+        assert np.array_equal(bits(np.concatenate(outs)), bits(g[f"y{k}"])), (a, r)
+    g2 = load_golden("g2_minmax")
+    x2, B2 = g2["x"], int(g2["B"])
+    mn, mx = np.zeros(C, np.float32), np.full(C, 10, np.float32)
+    for i in range(0, len(x2), B2):
+        xb = np.ascontiguousarray(x2[i:i + B2])
+        L.minmax_envelope(xb.ctypes.data_as(fp), mn.ctypes.data_as(fp), mx.ctypes.data_as(fp),
+                          np.float32(1e-4), np.float32(1e-5), np.float32(2.0), B2, C)
+        assert np.array_equal(bits(mn), bits(g2["mins"][i // B2])) and np.array_equal(bits(mx), bits(g2["maxs"][i // B2]))
+    g9 = load_golden("g9_backtrack")
+    lp = ctypes.POINTER(ctypes.c_long)
+    for k in range(3):
+        d = g9["deltas0"].copy()
+        buf = np.ascontiguousarray(g9["buf"])
+        ch = np.ascontiguousarray(g9["channels"])
+        L.backtrack_onsets(buf.ctypes.data_as(fp), ch.ctypes.data_as(lp), d.ctypes.data_as(lp),
+                           g9[f"alpha_{k}"], g9[f"tol_{k}"], buf.shape[0], len(ch), buf.shape[1], int(g9["B"]))
+        assert np.array_equal(d, g9[f"deltas_{k}"])
+
+
+def test_error_behaviour(det):
+    with pytest.raises(ctypes.ArgumentError):
+        det.AmplitudeOnsetDetector(2, 32)(np.zeros((32, 2), np.float64))
+    with pytest.raises(AssertionError):
+        det.AmplitudeOnsetDetector(2, 128, backtrack=True, backtrack_buffer_size=64)

@@ -1,0 +1,69 @@
+"""GPU parity of the classifier forwards (fp32 MFMA dense layers, Conv1d) against
+the reference's golden outputs and the numpy oracle; tolerance 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {"relu": torch.nn.ReLU, "silu": torch.nn.SiLU, "elu": torch.nn.ELU}
+
+
+def rel_err(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def test_fcnn_matches_reference_golden():
+    from onset_fingerprinting_amd.calibration import FCNN
+    g = load_golden("g8_models")
+    cfgs = {
+        "fc_a": dict(input_size=40, output_size=8),
+        "fc_b": dict(input_size=2, output_size=2, hidden_layers=[16, 12], activation=torch.nn.SiLU, batch_norm=False),
+        "fc_c": dict(input_size=14, output_size=3, hidden_layers=[32], activation=torch.nn.ELU, bias=False),
+    }
+    for name, kw in cfgs.items():
+        m = FCNN(**kw)
+        sd = {k.split("/", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + "/network")}
+        m.load_state_dict(sd)  # the reference's own state_dict keys load unchanged
+        m.eval()
+        x = g[f"{name}/x"]
+        y = m(torch.from_numpy(x)).numpy()
+        assert y.shape == g[f"{name}/y"].shape
+        assert rel_err(y, g[f"{name}/y"]) < 1e-4, name
+        ynp = {k: v.numpy() for k, v in sd.items()}
+        assert rel_err(y, oracle.fcnn_forward(ynp, x, activation=str(g[f"{name}/act"]))) < 1e-4
+        # call_np: one sample (calibration.py:552-560)
+        one = m.call_np(tuple(float(v) for v in x[0]))
+        assert one.shape == (kw["output_size"],) and rel_err(one, g[f"{name}/y"][0]) < 1e-4
+
+
+def test_fcnn_large_batch_and_ragged_rows():
+    from onset_fingerprinting_amd.calibration import FCNN
+    torch.manual_seed(0)
+    m = FCNN(40, 8).eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    for n in (1, 15, 17, 100003):
+        x = torch.randn(n, 40)
+        y = m(x.cuda()).cpu().numpy()
+        assert rel_err(y, oracle.fcnn_forward(sd, x.numpy())) < 1e-4
+
+
+def test_cnn_matches_reference_golden():
+    from onset_fingerprinting_amd.model import CNN
+    g = load_golden("g8_models")
+    for name, kw in (("cnn_a", dict(input_size=256, output_size=2, channels=4)),
+                     ("cnn_b", dict(input_size=64, output_size=3, channels=3, layer_sizes=[4, 6, 8],
+                                    kernel_size=5, padding=2))):
+        m = CNN(**kw).eval()
+        sd = {k.split("/", 1)[1]: torch.from_numpy(g[k]) for k in g.files
+              if k.startswith(name + "/") and k.split("/")[1] not in ("x", "y")}
+        m.load_state_dict(sd)
+        y = m(torch.from_numpy(g[f"{name}/x"])).numpy()
+        assert rel_err(y, g[f"{name}/y"]) < 1e-4, name

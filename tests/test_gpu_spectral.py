@@ -1,0 +1,138 @@
+"""GPU parity of framing / STFT / mel / MFCC against the numpy oracle and the
+reference's golden vectors.  Floating point: the north-star tolerance is 1e-4
+relative fp32; spectra are compared norm-wise (error relative to the largest
+magnitude of the frame set), which is how an fp32 FFT's error is distributed."""
+import ast
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def data():
+    from onset_fingerprinting_amd import data
+    return data
+
+
+def test_g6_stft_matches_reference_golden(data):
+    g = load_golden("g6_stft")
+    for k, case in enumerate(g["cases"]):
+        name, method, L, hop, nfft, hep, onset = ast.literal_eval(str(case))
+        S = data.stft(g[name], onset, L, hop, nfft, bool(hep), method)
+        ref = g[f"S{k}"]
+        assert S.shape == ref.shape and S.dtype == ref.dtype == np.complex64, (case, S.shape, ref.shape)
+        err = np.abs(S - ref).max() / np.abs(ref).max()
+        assert err < RTOL, (case, err)
+
+
+def test_stft_frame(data):
+    g = load_golden("g6_stft")
+    w = oracle.hann_periodic(256)
+    S = data.stft_frame(g["frame_x"], 256, w)
+    ref = g["frame_S"]
+    assert np.abs(S - ref).max() / np.abs(ref).max() < RTOL
+    # n_fft > len(x): centre padding (data.py:588-589)
+    w2 = oracle.pad_center(oracle.hann_periodic(256), 1024) if hasattr(oracle, "pad_center") else None
+    from oracle.spectral import pad_center
+    w2 = pad_center(oracle.hann_periodic(256), 1024)
+    S2 = data.stft_frame(g["frame_x"], 1024, w2)
+    ref2 = oracle.stft_frame(g["frame_x"], 1024, w2)
+    assert np.abs(S2 - ref2).max() / np.abs(ref2).max() < RTOL
+
+
+def test_stft_edges(data):
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(3000).astype(np.float32)
+    # onset near the end: the slice audio[onset:onset+L] is short (numpy semantics)
+    for method in ("zerozero", "prezero", "pre"):
+        try:
+            ref = oracle.stft(a, 2900, 256, 64, 256, False, method)
+        except ValueError:
+            continue
+        S = data.stft(a, 2900, 256, 64, 256, False, method)
+        assert S.shape == ref.shape
+        if ref.size:  # method "pre" leaves less than one frame here: empty result, as numpy gives
+            assert np.abs(S - ref).max() / max(np.abs(ref).max(), 1e-6) < RTOL
+    with pytest.raises(ValueError):
+        data.stft(a, 100, 256, 64, 100)  # unsupported n_fft
+
+
+@pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 3), (256, 64, 2), (512, 128, 1), (4096, 1024, 2)])
+def test_dense_power_matches_oracle(data, n_fft, hop, C):
+    import torch
+    rng = np.random.default_rng(n_fft)
+    N = n_fft * 6 + 37
+    x = (rng.standard_normal((2, N, C)) * np.exp(rng.uniform(-6, 0, (2, 1, C)))).astype(np.float32)
+    P = data.stft_power_dense(torch.from_numpy(x).cuda(), n_fft, hop).cpu().numpy()
+    for clip in range(2):
+        ref = oracle.dense_power_frames(x[clip], n_fft, hop)  # [C, H, bins] float64
+        assert P[clip].shape == ref.shape
+        for c in range(C):
+            err = np.abs(P[clip, c] - ref[c]).max() / ref[c].max()
+            assert err < RTOL, (clip, c, err)
+
+
+def test_dense_power_linearity_and_parseval_at_scale(data):
+    """Size-independent properties on a large input (full C2 size is covered by
+    bench.py's own check): Parseval against the windowed frame energy."""
+    import torch
+    rng = np.random.default_rng(9)
+    N, C, F, hop = 480000, 4, 1024, 256
+    x = rng.standard_normal((1, N, C)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    P = data.stft_power_dense(xd, F, hop)
+    H = P.shape[2]
+    w = oracle.hann_periodic(F)
+    # Parseval for a real signal: sum_k c_k |X_k|^2 = F * sum_n (w x)^2, c = 1 at DC/Nyquist else 2
+    wts = torch.full((F // 2 + 1,), 2.0, device="cuda")
+    wts[0] = wts[-1] = 1.0
+    lhs = (P[0] * wts).sum(-1).cpu().numpy()  # [C, H]
+    for h in (0, 1, H // 2, H - 1):
+        for c in range(C):
+            seg = x[0, h * hop:h * hop + F, c].astype(np.float64) * w
+            assert abs(lhs[c, h] - F * (seg ** 2).sum()) / (F * (seg ** 2).sum()) < RTOL
+    P2 = data.stft_power_dense(2.0 * xd, F, hop)
+    assert torch.allclose(P2, 4.0 * P, rtol=1e-5, atol=0)
+
+
+def test_g7_frame_extractor_exact(data):
+    g = load_golden("g7_frames")
+    a, o = g["audio"], g["onsets"]
+    assert np.array_equal(data.FrameExtractor(256, 16)(a, o), g["f1"])
+    assert np.array_equal(data.FrameExtractor(256, 16, use_min_onset=False)(a, o), g["f2"])
+    assert np.array_equal(data.FrameExtractor(128, 32, add_pre_samples=True)(a, o), g["f3"])
+    assert np.array_equal(data.FrameExtractor(64, 8)(a[:, 0].copy(), o[:, 0]), g["f1d"])
+    with pytest.raises(IndexError):
+        data.FrameExtractor(256, 16)(a, np.array([[4900, 4900, 4900, 4900]]))
+
+
+def test_mel_and_mfcc_match_oracle(data):
+    """PARITY UNPINNED vs librosa (absent): compared with the oracle's restatement
+    of librosa's published definition, plus known answers."""
+    rng = np.random.default_rng(3)
+    S = (rng.standard_normal((2, 513, 7)) + 1j * rng.standard_normal((2, 513, 7))).astype(np.complex64)
+    S[:, :, 3] *= 1e-7  # exercises the top_db floor
+    got = data.cspec_to_mfcc(S, 48000)
+    ref = oracle.cspec_to_mfcc(S, 48000)
+    assert got.shape == ref.shape == (2, 14, 7)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < RTOL
+    fb = data.mel_filterbank(48000, 1024, 40)
+    assert np.allclose(fb, oracle.mel_filterbank(48000, 1024, 40), rtol=1e-6, atol=1e-9)
+    # known answers: every band is a triangle with Slaney area normalisation
+    assert fb.shape == (40, 513) and (fb >= 0).all() and (fb.sum(1) > 0).all()
+    S1 = data.cspec_to_mfcc(S[0], 48000, n_mels=20, n_mfcc=5, fmax=16000)
+    assert np.abs(S1 - oracle.cspec_to_mfcc(S[0], 48000, n_mels=20, n_mfcc=5, fmax=16000)).max() < 1e-3
+
+
+def test_window_contribution_weights(data):
+    g = load_golden("g10_wcw")
+    w = oracle.hann_periodic(1024)
+    np.testing.assert_allclose(data.window_contribution_weights(w, 256), g["w1024_256"], rtol=1e-12)
+    np.testing.assert_allclose(data.window_contribution_weights(w, 256, True), g["w1024_256_hep"], rtol=1e-12)
