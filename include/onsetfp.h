@@ -126,8 +126,12 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  *              only cap_per_clip are stored)
  *   d_ws       work space of at least ofp_detect_workspace_bytes()
  * Synchronises `stream` internally (the speculative passes are verified on the
- * host); on return all outputs are complete.  h_info (optional, host) receives
- * {hp passes, follower passes, tracker passes, repaired chunks}. */
+ * host); on return all outputs are complete.  h_info (optional, host, int64
+ * [OFP_DETECT_INFO_LEN]) receives {0: hp passes, 1: follower passes, 2: tracker
+ * passes, 3: repaired chunks, 4..9: nanoseconds (HIP events on `stream`) spent in
+ * the hp, dB, follower, linear, tracker and crossing/state-machine stages,
+ * 10: total nanoseconds}. */
+#define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
                        int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info,

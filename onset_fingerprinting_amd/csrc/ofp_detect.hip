@@ -580,6 +580,7 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_on_f, onf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
+    for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
     if (e != hipSuccess) {
         ofp_detector_destroy(d);
         return ofp::fail(OFP_ERR_HIP, "ofp_detector_create: %s", hipGetErrorString(e));
@@ -593,6 +594,8 @@ int ofp_detector_destroy(ofp_detector* d) {
     if (d->d_on_f) (void)hipFree(d->d_on_f);
     if (d->d_off_f) (void)hipFree(d->d_off_f);
     if (d->d_on_d) (void)hipFree(d->d_on_d);
+    for (int k = 0; k < 8; ++k)
+        if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     delete d;
     return OFP_OK;
 }
@@ -627,7 +630,9 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     float* xdb = reinterpret_cast<float*>(ws + l.o_xdb);
     float* dif = reinterpret_cast<float*>(ws + l.o_dif);
     int* d_changed = reinterpret_cast<int*>(ws + l.o_flags);
-    int64_t info[4] = {0, 0, 0, 0};
+    int64_t info[OFP_DETECT_INFO_LEN] = {0};
+    hipEvent_t* ev = d->ev;
+    OFP_HIP(hipEventRecord(ev[0], stream));
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
         OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
         OFP_HIP(hipStreamSynchronize(stream));
@@ -652,9 +657,11 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                            &info[0], &info[3]);
         if (rc != OFP_OK) return rc;
     }
+    OFP_HIP(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, d_x, xdb, n_clips,
                        p.hp_enabled ? 0 : 1, p.floor_db);
     OFP_LAUNCH_CHECK("k_rect_db");
+    OFP_HIP(hipEventRecord(ev[2], stream));
 
     // --- followers
     {
@@ -674,9 +681,11 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                            stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
+    OFP_HIP(hipEventRecord(ev[3], stream));
     hipLaunchKernelGGL(k_rel_linear, dim3(ew_grid), dim3(256), 0, stream, g, dif, d_rel, n_clips,
                        p.floor_db);
     OFP_LAUNCH_CHECK("k_rel_linear");
+    OFP_HIP(hipEventRecord(ev[4], stream));
     const float* rel = dif;
 
     // --- tracker (relative thresholds only; in manual mode its state is never read)
@@ -704,6 +713,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (rc != OFP_OK) return rc;
     }
 
+    OFP_HIP(hipEventRecord(ev[5], stream));
     // --- crossings per block, then the hysteresis state machine
     ScanArgs sa;
     sa.g = g;
@@ -754,7 +764,19 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
         OFP_LAUNCH_CHECK("k_backtrack");
     }
+    OFP_HIP(hipEventRecord(ev[6], stream));
     OFP_HIP(hipStreamSynchronize(stream));
+    // stage durations in nanoseconds (HIP events on the launch stream)
+    for (int k = 0; k < 6; ++k) {
+        float ms = 0.0f;
+        OFP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        info[4 + k] = (int64_t)(ms * 1.0e6);
+    }
+    {
+        float ms = 0.0f;
+        OFP_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
+        info[10] = (int64_t)(ms * 1.0e6);
+    }
     if (h_info) std::memcpy(h_info, info, sizeof(info));
     return OFP_OK;
 }

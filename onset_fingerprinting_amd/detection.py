@@ -146,13 +146,17 @@ class BatchDetector:
                 "counts": torch.zeros(n_clips, dtype=torch.int64, device=x.device),
                 "rel": torch.empty((n_clips, nb * B, C), dtype=torch.float32, device=x.device) if want_rel else None,
             }
-        info = (ctypes.c_int64 * 4)()
+        info = (ctypes.c_int64 * 16)()
         rel = out["rel"]
         check(self.d.lib.ofp_detect_offline(
             self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
             out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
             _stream_ptr(x.device)), "ofp_detect_offline")
-        self.last_info = dict(hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3])
+        self.last_info = dict(
+            hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3],
+            # stage durations, HIP events on the launch stream (milliseconds)
+            stage_ms=dict(hp=info[4] / 1e6, db=info[5] / 1e6, ar=info[6] / 1e6, rel=info[7] / 1e6,
+                          mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6))
         out["cap"] = cap
         return out
 

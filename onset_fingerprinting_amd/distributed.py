@@ -1,0 +1,61 @@
+"""Multi-GPU form of the path: clips shard across ranks (one process per GPU),
+no data-path collective; one exchange at the end collates the onset records
+(SURVEY.md section 8e): an all-gather of the per-rank record counts followed by
+an all-gather of the records padded to the largest count.  On ROCm the "nccl"
+backend of torch.distributed is RCCL over xGMI; the payload is KBs, so the
+exchange is latency-bound and a ring all-reduce is never needed.
+
+Channels of one detector instance are coupled (detection.py:790), so a clip is
+never split across ranks; a single long stream does not shard at all ("replicas
+only").
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ONSET_DTYPE = np.dtype([("clip", np.int32), ("channel", np.int32), ("sample", np.int64)])
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous block partition (first `n_items % world_size` ranks get one more)."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def flatten_records(records, counts, cap, clip_offset=0):
+    """[n_clips, cap, 16] uint8 + counts -> [total, 16] uint8 with global clip ids
+    (on the tensors' device; no host round trip)."""
+    n_clips = counts.numel()
+    idx = torch.arange(cap, device=records.device)[None, :] < counts.clamp(max=cap)[:, None]
+    flat = records.reshape(n_clips, cap, 16)[idx]
+    if clip_offset and flat.numel():
+        clip = flat[:, :4].contiguous().view(torch.int32)
+        clip += int(clip_offset)
+        flat[:, :4] = clip.view(torch.uint8)
+    return flat.contiguous()
+
+
+def all_gather_onsets(local_records, group=None):
+    """local_records: [n_local, 16] uint8 (ofp_onset structs) on this rank's device.
+    Returns the concatenation over ranks, in rank order, on every rank."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_records
+    world = dist.get_world_size(group)
+    dev = local_records.device
+    n_local = torch.tensor([local_records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    if m == 0:
+        return local_records[:0]
+    padded = torch.zeros((m, 16), dtype=torch.uint8, device=dev)
+    padded[: local_records.shape[0]] = local_records
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def records_to_numpy(flat):
+    return flat.cpu().numpy().reshape(-1, 16).view(ONSET_DTYPE).reshape(-1)

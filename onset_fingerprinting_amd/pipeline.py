@@ -1,0 +1,81 @@
+"""The whole hot path, HBM-resident: detect -> rFFT power -> mel fingerprint ->
+classify, for a batch of clips [n_clips, N, C] on one GPU.
+
+This is the composition BASELINE.json's metric names ("detect+FFT+classify").
+The reference never composes these steps in one function (its callers are
+notebooks and the realtime callback); each step here is
+the drop-in of the corresponding reference function:
+
+  detect    detection.detect_onsets_amplitude   (detection.py:19-86)
+  rFFT      data.stft_frame on every hop         (data.py:581-590; "dense
+            equivalent" of SURVEY.md 8a row a9)
+  mel       the mel step of data.cspec_to_mfcc   (data.py:674-676)
+  classify  calibration.FCNN.forward             (calibration.py:520-527)
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .calibration import FCNN
+from .data import MelBank, stft_power_dense
+from .detection import BatchDetector
+
+
+def seeded_fcnn(n_in=40, n_out=8, seed=1234):
+    """FCNN(n_in -> [10,10,10] -> n_out) with deterministic synthetic weights and
+    non-trivial BatchNorm statistics (there is no trained checkpoint in the reference)."""
+    g = torch.Generator().manual_seed(seed)
+    m = FCNN(n_in, n_out)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) / np.sqrt(mod.in_features))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(0.2 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+    return m.eval()
+
+
+class FingerprintPipeline:
+    def __init__(self, n_channels, n_fft=1024, hop=256, sr=48000, n_mels=40, classifier=None, device=0,
+                 **detector_kwargs):
+        self.device = torch.device("cuda", int(device))
+        _lib.require_gpu(int(device))
+        self.n_channels, self.n_fft, self.hop, self.sr, self.n_mels = n_channels, n_fft, hop, sr, n_mels
+        self.detector = BatchDetector(n_channels, block_size=hop, sr=sr, device=device, **detector_kwargs)
+        self.mel = MelBank(sr, n_fft, n_mels, device=device)
+        self.classifier = classifier if classifier is not None else seeded_fcnn(n_mels, 8)
+        self._bufs = None
+
+    def n_frames(self, n_samples):
+        return 0 if n_samples < self.n_fft else 1 + (n_samples - self.n_fft) // self.hop
+
+    def _buffers(self, n_clips, N):
+        key = (n_clips, N)
+        if self._bufs is None or self._bufs["key"] != key:
+            C, H, bins = self.n_channels, self.n_frames(N), self.n_fft // 2 + 1
+            nb = N // self.hop
+            dev = self.device
+            self._bufs = dict(
+                key=key,
+                det=dict(records=torch.empty((n_clips, max(1, min(nb * C, 1 << 16)), 16), dtype=torch.uint8, device=dev),
+                         counts=torch.zeros(n_clips, dtype=torch.int64, device=dev),
+                         rel=torch.empty((n_clips, nb * self.hop, C), dtype=torch.float32, device=dev)),
+                power=torch.empty((n_clips, C, H, bins), dtype=torch.float32, device=dev),
+                mel=torch.empty((n_clips, C, H, self.n_mels), dtype=torch.float32, device=dev),
+            )
+            self.detector.reserve(n_clips, N, int(0.5 * self.sr))
+        return self._bufs
+
+    def run(self, x):
+        """x float32 CUDA [n_clips, N, C] -> dict(records, counts, cap, rel, power, mel, logits)."""
+        n_clips, N, C = x.shape
+        b = self._buffers(n_clips, N)
+        det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1])
+        power = stft_power_dense(x, self.n_fft, self.hop, out=b["power"])
+        mel = self.mel(power, out=b["mel"])
+        logits = self.classifier(mel.reshape(-1, self.n_mels))
+        return dict(records=det["records"], counts=det["counts"], cap=det["cap"], rel=det["rel"], power=power,
+                    mel=mel, logits=logits.reshape(n_clips, C, -1, logits.shape[-1]),
+                    info=self.detector.last_info)
