@@ -156,19 +156,22 @@ OFP_HD float ofp_ar_step(float x, float y, float attack, float release) {
 
 /* One step of the EMA min tracker: envelope_follower.c:39-45. */
 OFP_HD float ofp_min_step(float x, float mn, float ialpha, float alpha, float minmin) {
-    if (x < minmin) return minmin;
-    if (x < mn) return x;
+    /* branch-free form of: if (x < minmin) minmin; else if (x < mn) x; else ema */
     float a = mn * ialpha;
     float b = x * alpha;
-    return a + b;
+    float r = a + b;
+    r = x < mn ? x : r;
+    r = x < minmin ? minmin : r;
+    return r;
 }
 
 /* One step of the EMA max tracker: envelope_follower.c:47-51. */
 OFP_HD float ofp_max_step(float x, float mx, float ialpha, float alpha) {
-    if (x > mx) return x;
+    /* branch-free form of: if (x > mx) x; else ema */
     float a = mx * ialpha;
     float b = x * alpha;
-    return a + b;
+    float r = a + b;
+    return x > mx ? x : r;
 }
 
 /* (float)(1.0 - alpha): envelope_follower.c:31-32, fp64 subtract then fp32 store */

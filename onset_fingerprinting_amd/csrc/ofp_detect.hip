@@ -60,107 +60,221 @@ __host__ __device__ inline int64_t hp_dst(const Geom& g, int64_t v) {
 __host__ __device__ inline int64_t u_src(const Geom& g, int64_t u) { return u < g.n_wb ? u : u - g.n_wb; }
 
 // ---------------------------------------------------------------------------
-// stages
+// stages.  Each stage describes one sequential recurrence over a stream:
+//   NS / State      the carried state words
+//   NBRK / brk(i)   stream positions where the stream<->memory mapping changes
+//                   (between two breaks input and output addresses are affine in
+//                   the position, so the inner loop only increments pointers)
+//   in_ptr/out_ptr  address of element (clip, c, pos); out_ptr may be null
+//   compute         one step (include/ofp_math.h), returns the dense output value
 struct HpStage {
     static constexpr int NS = 4;
+    static constexpr int NBRK = 2;
+    static constexpr bool DENSE_OUT = true;
     struct State { float z[4]; };
+    struct Sparse { int rem; };
     Geom g;
     const float* x;  // [clips][N][C]
     float* out;      // [clips][U][C]
     float b[5], a[5];
     int64_t L, W, n_chunks;
     __device__ int64_t len() const { return g.V; }
+    __device__ int64_t brk(int i) const { return i == 0 ? g.n_wb : g.n_w; }
     __device__ State init(int64_t, int) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
     __device__ State guess(int64_t, int, int64_t) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
-    __device__ float load(int64_t clip, int c, int64_t v) const {
-        return x[(clip * g.N + hp_src(g, v)) * g.C + c];
+    __device__ const float* in_ptr(int64_t clip, int c, int64_t v) const {
+        return x + (clip * g.N + hp_src(g, v)) * g.C + c;
     }
-    template <bool OUT>
-    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t v) const {
-        float y = ofp_df2t4_step(xv, b, a, s.z);
-        if (OUT) {
-            int64_t u = hp_dst(g, v);
-            if (u >= 0) out[(clip * g.U + u) * g.C + c] = y;
-        }
+    __device__ float* out_ptr(int64_t clip, int c, int64_t v) const {
+        int64_t u = hp_dst(g, v);
+        return u >= 0 ? out + (clip * g.U + u) * g.C + c : nullptr;
     }
+    __device__ float compute(State& s, float xv) const { return ofp_df2t4_step(xv, b, a, s.z); }
+    __device__ Sparse sparse_begin(int64_t, int, int64_t) const { return Sparse{-1}; }
+    __device__ void sparse_step(Sparse&, const State&) const {}
 };
 
 struct ArStage {
     static constexpr int NS = 2;
+    static constexpr int NBRK = 0;
+    static constexpr bool DENSE_OUT = true;
     struct State { float z[2]; };  // yf, ys
+    struct Sparse { int rem; };
     Geom g;
     const float* xdb;  // [clips][U][C]
     float* dif;        // [clips][U][C]
     float fa, fr, sa, sr, floor_db;
     int64_t L, W, n_chunks;
     __device__ int64_t len() const { return g.U; }
+    __device__ int64_t brk(int) const { return 0; }
     __device__ State init(int64_t, int) const { return State{{floor_db, floor_db}}; }
     __device__ State guess(int64_t clip, int c, int64_t u) const {
-        float v = load(clip, c, u);
+        float v = *in_ptr(clip, c, u);
         return State{{v, v}};
     }
-    __device__ float load(int64_t clip, int c, int64_t u) const { return xdb[(clip * g.U + u) * g.C + c]; }
-    template <bool OUT>
-    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t u) const {
+    __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return xdb + (clip * g.U + u) * g.C + c; }
+    __device__ float* out_ptr(int64_t clip, int c, int64_t u) const { return dif + (clip * g.U + u) * g.C + c; }
+    __device__ float compute(State& s, float xv) const {
         s.z[0] = ofp_ar_step(xv, s.z[0], fa, fr);
         s.z[1] = ofp_ar_step(xv, s.z[1], sa, sr);
-        if (OUT) dif[(clip * g.U + u) * g.C + c] = s.z[0] - s.z[1];
+        return s.z[0] - s.z[1];
     }
+    __device__ Sparse sparse_begin(int64_t, int, int64_t) const { return Sparse{-1}; }
+    __device__ void sparse_step(Sparse&, const State&) const {}
 };
 
 struct MmStage {
     static constexpr int NS = 2;
+    static constexpr int NBRK = 1;
+    static constexpr bool DENSE_OUT = false;
     struct State { float z[2]; };  // mn, mx
+    struct Sparse {                 // writes the tracker state after each MAIN block
+        float* pmn;
+        float* pmx;
+        int rem;     // steps until the next block end (<0: warm-up region, no output)
+        int stride;  // C
+        int B;
+    };
     Geom g;
     const float* rel;  // [clips][U][C]
-    float* thr_mn;     // [clips][nb][C] tracker state after each MAIN block
+    float* thr_mn;     // [clips][nb][C]
     float* thr_mx;
     float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
     int64_t nb;
     int64_t L, W, n_chunks;
     __device__ int64_t len() const { return g.U; }
+    __device__ int64_t brk(int) const { return g.n_wb; }
     __device__ State init(int64_t, int) const { return State{{min0, max0}}; }
     __device__ State guess(int64_t, int, int64_t) const { return State{{minmin, 0.f}}; }
-    __device__ float load(int64_t clip, int c, int64_t u) const { return rel[(clip * g.U + u) * g.C + c]; }
-    template <bool OUT>
-    __device__ void step(State& s, float xv, int64_t clip, int c, int64_t u) const {
+    __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return rel + (clip * g.U + u) * g.C + c; }
+    __device__ float* out_ptr(int64_t, int, int64_t) const { return nullptr; }
+    __device__ float compute(State& s, float xv) const {
         s.z[0] = ofp_min_step(xv, s.z[0], ialpha_min, alpha_min, minmin);
         s.z[1] = ofp_max_step(xv, s.z[1], ialpha_max, alpha_max);
-        if (OUT) {
-            int64_t m = u - g.n_wb;
-            if (m >= 0 && (m + 1) % g.B == 0) {
-                int64_t j = m / g.B;
-                thr_mn[(clip * nb + j) * g.C + c] = s.z[0];
-                thr_mx[(clip * nb + j) * g.C + c] = s.z[1];
-            }
+        return 0.0f;
+    }
+    __device__ Sparse sparse_begin(int64_t clip, int c, int64_t u) const {
+        Sparse sp;
+        sp.stride = g.C;
+        sp.B = g.B;
+        int64_t m = u - g.n_wb;
+        if (m < 0) {
+            sp.rem = -1;
+            sp.pmn = sp.pmx = nullptr;
+        } else {
+            int64_t j = m / g.B;
+            sp.rem = (int)(g.B - 1 - (m - j * g.B));
+            sp.pmn = thr_mn + (clip * nb + j) * g.C + c;
+            sp.pmx = thr_mx + (clip * nb + j) * g.C + c;
         }
+        return sp;
+    }
+    __device__ void sparse_step(Sparse& sp, const State& s) const {
+        if (sp.rem == 0) {
+            *sp.pmn = s.z[0];
+            *sp.pmx = s.z[1];
+            sp.pmn += sp.stride;
+            sp.pmx += sp.stride;
+            sp.rem = sp.B;
+        }
+        sp.rem -= 1;
     }
 };
 
-// run t in [t0, t1) with register prefetch of the (state-independent) inputs
+// run positions [t0, t1) of an affine span: inputs are prefetched PB steps ahead
+// into registers (their addresses do not depend on the state), pointers advance
+// by C floats per step.  HAS_OUT / SPARSE are decided once per span so the step
+// sequence itself is straight-line code.
+template <class S, bool HAS_OUT, bool SPARSE, int PB>
+__device__ __forceinline__ void process_batch(const S& st, typename S::State& s, const float (&v)[PB], float*& op,
+                                              typename S::Sparse& sp, int64_t stride) {
+    if (SPARSE && sp.rem < PB) {  // a block ends inside this batch (once every B/PB batches)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            st.compute(s, v[i]);
+            st.sparse_step(sp, s);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            float o = st.compute(s, v[i]);
+            if (HAS_OUT) op[i * stride] = o;
+        }
+        if (HAS_OUT) op += PB * stride;
+        if (SPARSE) sp.rem -= PB;
+    }
+}
+
+template <class S, bool HAS_OUT, bool SPARSE>
+__device__ __forceinline__ void run_affine_impl(const S& st, typename S::State& s, const float* ip, float* op,
+                                                typename S::Sparse sp, int64_t n) {
+    constexpr int PB = 16;
+    const int64_t stride = st.g.C;
+    float A[PB], Bv[PB];
+    if (n >= PB) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) A[i] = ip[i * stride];
+        ip += PB * stride;
+        n -= PB;
+        // two batches per iteration, ping-pong between the register sets (no copies)
+        while (n >= 2 * PB) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) Bv[i] = ip[i * stride];
+            ip += PB * stride;
+            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) A[i] = ip[i * stride];
+            ip += PB * stride;
+            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, Bv, op, sp, stride);
+            n -= 2 * PB;
+        }
+        if (n >= PB) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) Bv[i] = ip[i * stride];
+            ip += PB * stride;
+            n -= PB;
+            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
+            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, Bv, op, sp, stride);
+        } else {
+            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
+        }
+    }
+    for (; n > 0; --n) {
+        float o = st.compute(s, *ip);
+        ip += stride;
+        if (HAS_OUT) { *op = o; op += stride; }
+        if (SPARSE) st.sparse_step(sp, s);
+    }
+}
+
+template <class S, bool OUT>
+__device__ __forceinline__ void run_affine(const S& st, typename S::State& s, int64_t clip, int c,
+                                           int64_t t0, int64_t t1) {
+    const float* ip = st.in_ptr(clip, c, t0);
+    float* op = (OUT && S::DENSE_OUT) ? st.out_ptr(clip, c, t0) : nullptr;
+    typename S::Sparse sp = st.sparse_begin(clip, c, t0);
+    const bool sparse = OUT && !S::DENSE_OUT && sp.rem >= 0;
+    const int64_t n = t1 - t0;
+    if (S::DENSE_OUT) {
+        if (op) run_affine_impl<S, true, false>(st, s, ip, op, sp, n);
+        else run_affine_impl<S, false, false>(st, s, ip, op, sp, n);
+    } else {
+        if (sparse) run_affine_impl<S, false, true>(st, s, ip, op, sp, n);
+        else run_affine_impl<S, false, false>(st, s, ip, op, sp, n);
+    }
+}
+
 template <class S, bool OUT>
 __device__ __forceinline__ void run_span(const S& st, typename S::State& s, int64_t clip, int c,
                                          int64_t t0, int64_t t1) {
-    constexpr int PB = 8;
-    float cur[PB], nxt[PB];
-    int64_t t = t0;
-    if (t + PB <= t1) {
+    int64_t a = t0;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) cur[i] = st.load(clip, c, t + i);
-        while (t + 2 * PB <= t1) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) nxt[i] = st.load(clip, c, t + PB + i);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) st.template step<OUT>(s, cur[i], clip, c, t + i);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) cur[i] = nxt[i];
-            t += PB;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) st.template step<OUT>(s, cur[i], clip, c, t + i);
-        t += PB;
+    for (int i = 0; i <= S::NBRK; ++i) {
+        int64_t b = t1;
+        if (i < S::NBRK) b = min(max(st.brk(i), a), t1);
+        if (b > a) run_affine<S, OUT>(st, s, clip, c, a, b);
+        a = b;
     }
-    for (; t < t1; ++t) st.template step<OUT>(s, st.load(clip, c, t), clip, c, t);
 }
 
 // One chunk-Jacobi pass.  Thread = (clip, chunk, channel), channel fastest.
@@ -335,60 +449,121 @@ struct SmArgs {
     int32_t clip_base;   // added to record.clip
 };
 
+// Event-driven: the crossing tables are staged through LDS a tile of blocks at a
+// time (coalesced, one tile ahead); while no channel is latched the wave jumps
+// straight to the next block that holds a candidate crossing and advances the
+// cooldown counters in closed form over the skipped blocks.
+constexpr int SM_NPL = 16;  // table entries per lane per tile (TB*C <= 64*SM_NPL)
+
 __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
-    extern __shared__ unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char smem[];
     const int C = a.g.C, B = a.g.B;
     const int64_t clip = blockIdx.x;
     const int lane = threadIdx.x;
-    // per-channel state in LDS (C may exceed 64)
+    const int TB = max(1, min(64, (64 * SM_NPL) / C));  // blocks per tile
     int64_t* deb = reinterpret_cast<int64_t*>(smem);          // [C]
     int32_t* onidx = reinterpret_cast<int32_t*>(deb + C);     // [C]
-    uint8_t* state = reinterpret_cast<uint8_t*>(onidx + C);   // [C]
+    int32_t* t_fc = onidx + C;                                // [TB*C]
+    int32_t* t_lb = t_fc + TB * C;                            // [TB*C]
+    uint8_t* state = reinterpret_cast<uint8_t*>(t_lb + TB * C);  // [C]
     uint8_t* onflag = state + C;                              // [C]
     for (int c = lane; c < C; c += 64) {
         deb[c] = 0;
         state[c] = 0;
     }
-    __syncthreads();
     int64_t count = 0;
     ofp_onset* rec = a.records + clip * a.cap;
-    for (int64_t j = 0; j < a.nb; ++j) {
-        const int32_t* fc = a.first_cross + (clip * a.nb + j) * C;
-        const int32_t* lb = a.last_below + (clip * a.nb + j) * C;
-        int mx = 0;
-        for (int c = lane; c < C; c += 64) {
-            int f = fc[c];
-            bool gate = !state[c] && deb[c] < 1;      // :764-768 (block-start values)
-            bool on = gate && f >= 0;
-            onflag[c] = on;
-            int oi = on ? f : 0;                      // :774 argmax of an all-False column is 0
-            onidx[c] = oi;
-            mx = max(mx, oi);
+    const int32_t* fc_g = a.first_cross + clip * a.nb * C;
+    const int32_t* lb_g = a.last_below + clip * a.nb * C;
+    int32_t rf[SM_NPL], rl[SM_NPL];
+    auto load_tile = [&](int64_t j0) {
+        const int64_t n = min<int64_t>(TB, a.nb - j0) * C;
+#pragma unroll
+        for (int i = 0; i < SM_NPL; ++i) {
+            const int64_t e = lane + 64 * i;
+            rf[i] = e < n ? fc_g[j0 * C + e] : -1;
+            rl[i] = e < n ? lb_g[j0 * C + e] : -1;
         }
-        // :790 on_indices.max() over ALL channels
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-        for (int c0 = 0; c0 < C; c0 += 64) {
-            int c = c0 + lane;
-            bool on = false;
-            if (c < C) {
-                on = onflag[c];
-                if (on) {                              // :778-779
-                    state[c] = 1;
-                    deb[c] = a.cooldown;
-                }
-                if (deb[c] > 0) deb[c] -= B;           // :780
-                if (lb[c] >= mx) state[c] = 0;         // :784-791 (any row >= mx below off)
+    };
+    auto put_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < SM_NPL; ++i) {
+            const int e = lane + 64 * i;
+            if (e < TB * C) {
+                t_fc[e] = rf[i];
+                t_lb[e] = rl[i];
             }
-            unsigned long long m = __ballot(on);
-            if (on) {
-                int64_t pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < a.cap) {
-                    rec[pos].clip = (int32_t)clip + a.clip_base;
-                    rec[pos].channel = c;
-                    rec[pos].sample = j * B + onidx[c];  // detection.py:80
+        }
+    };
+    bool any_latched = false;  // wave-uniform: some channel has state == 1
+    if (a.nb > 0) load_tile(0);
+    for (int64_t j0 = 0; j0 < a.nb; j0 += TB) {
+        __syncthreads();
+        put_tile();
+        __syncthreads();
+        if (j0 + TB < a.nb) load_tile(j0 + TB);
+        const int nblk = (int)min<int64_t>(TB, a.nb - j0);
+        // candidate blocks of this tile: any channel with an upward crossing
+        bool cand = false;
+        if (lane < nblk)
+            for (int c = 0; c < C; ++c) cand |= t_fc[lane * C + c] >= 0;
+        const unsigned long long cmask = __ballot(cand);
+        int bi = 0;
+        while (bi < nblk) {
+            if (!any_latched) {
+                const unsigned long long rest = cmask >> bi;
+                const int skip = rest ? __builtin_ctzll(rest) : (nblk - bi);
+                if (skip > 0) {  // nothing can fire: only the cooldown counters move (:780)
+                    for (int c = lane; c < C; c += 64) {
+                        int64_t d = deb[c];
+                        if (d > 0) deb[c] = d - (int64_t)B * min<int64_t>(skip, (d + B - 1) / B);
+                    }
+                    bi += skip;
+                    if (bi >= nblk) break;
                 }
             }
-            count += __popcll(m);
+            const int64_t j = j0 + bi;
+            const int32_t* fc = t_fc + bi * C;
+            const int32_t* lb = t_lb + bi * C;
+            int mx = 0;
+            for (int c = lane; c < C; c += 64) {
+                int f = fc[c];
+                bool gate = !state[c] && deb[c] < 1;      // :764-768 (block-start values)
+                bool on = gate && f >= 0;
+                onflag[c] = on;
+                int oi = on ? f : 0;                      // :774 argmax of an all-False column is 0
+                onidx[c] = oi;
+                mx = max(mx, oi);
+            }
+            // :790 on_indices.max() over ALL channels
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+            bool latched = false;
+            for (int c0 = 0; c0 < C; c0 += 64) {
+                int c = c0 + lane;
+                bool on = false;
+                if (c < C) {
+                    on = onflag[c];
+                    if (on) {                              // :778-779
+                        state[c] = 1;
+                        deb[c] = a.cooldown;
+                    }
+                    if (deb[c] > 0) deb[c] -= B;           // :780
+                    if (lb[c] >= mx) state[c] = 0;         // :784-791 (any row >= mx below off)
+                    latched |= state[c] != 0;
+                }
+                unsigned long long m = __ballot(on);
+                if (on) {
+                    int64_t pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < a.cap) {
+                        rec[pos].clip = (int32_t)clip + a.clip_base;
+                        rec[pos].channel = c;
+                        rec[pos].sample = j * B + onidx[c];  // detection.py:80
+                    }
+                }
+                count += __popcll(m);
+            }
+            any_latched = __ballot(latched) != 0ull;
+            ++bi;
         }
     }
     if (lane == 0) a.counts[clip] = count;
@@ -504,39 +679,54 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     return l;
 }
 
-// chunk-Jacobi driver for one stage; returns passes run (>=1) or a negative error
+// chunk-Jacobi driver for one stage; returns OFP_OK or an error
+template <class S>
+int launch_pass(const char* name, const S& st, int pass, int64_t n_threads, const uint32_t* prev, uint32_t* next,
+                uint32_t* used, int* d_changed, hipStream_t stream) {
+    const unsigned grid = (unsigned)cdiv(n_threads, 64);
+    hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(64), 0, stream, st, pass, n_threads, prev, next, used,
+                       d_changed);
+    OFP_LAUNCH_CHECK(name);
+    return OFP_OK;
+}
+
+// d_changed: int[OFP_MAX_GROUP]; passes are launched in groups of `group` between host
+// synchronisations (a converged stage makes the surplus passes of a group no-ops).
+constexpr int OFP_MAX_GROUP = 16;
+
 template <class S>
 int run_stage(const char* name, S st, int64_t n_clips, unsigned char* ws, int64_t o_state,
-              int* d_changed, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
+              int* d_changed, int group, int max_passes, hipStream_t stream, int64_t* passes,
+              int64_t* repaired) {
     const int64_t n_threads = n_clips * st.n_chunks * st.g.C;
     const int64_t words = n_threads * S::NS;
     uint32_t* used = reinterpret_cast<uint32_t*>(ws + o_state);
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
-    const int block = 64;
-    const unsigned grid = (unsigned)cdiv(n_threads, block);
-    hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(block), 0, stream, st, 0, n_threads,
-                       (const uint32_t*)endB, endA, used, d_changed);
-    OFP_LAUNCH_CHECK(name);
+    int rc = launch_pass(name, st, 0, n_threads, (const uint32_t*)endB, endA, used, d_changed, stream);
+    if (rc != OFP_OK) return rc;
     *passes = 1;
     if (st.n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
     uint32_t* prev = endA;
     uint32_t* next = endB;
-    for (int pass = 1;; ++pass) {
-        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(block), 0, stream, st, pass, n_threads,
-                           (const uint32_t*)prev, next, used, d_changed);
-        OFP_LAUNCH_CHECK(name);
-        int changed = 0;
-        OFP_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+    group = std::max(1, std::min(group, OFP_MAX_GROUP));
+    for (int pass = 1;;) {
+        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int) * OFP_MAX_GROUP, stream));
+        for (int gidx = 0; gidx < group; ++gidx, ++pass) {
+            rc = launch_pass(name, st, pass, n_threads, (const uint32_t*)prev, next, used,
+                             d_changed + gidx, stream);
+            if (rc != OFP_OK) return rc;
+            std::swap(prev, next);
+            *passes += 1;
+        }
+        int changed[OFP_MAX_GROUP];
+        OFP_HIP(hipMemcpyAsync(changed, d_changed, sizeof(int) * group, hipMemcpyDeviceToHost, stream));
         OFP_HIP(hipStreamSynchronize(stream));
-        *passes += 1;
-        std::swap(prev, next);
-        if (changed == 0) break;
-        *repaired += changed;
-        if (max_passes > 0 && pass >= max_passes)
+        for (int gidx = 0; gidx < group; ++gidx) *repaired += changed[gidx];
+        if (changed[group - 1] == 0) break;
+        if (max_passes > 0 && pass > max_passes)
             return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name,
-                             changed, pass);
+                             changed[group - 1], pass - 1);
     }
     return OFP_OK;
 }
@@ -653,8 +843,8 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         st.L = l.hp_L;
         st.W = l.hp_W;
         st.n_chunks = l.hp_chunks;
-        int rc = run_stage("hp stage", st, n_clips, ws, l.o_hp_state, d_changed, d->t.max_passes, stream,
-                           &info[0], &info[3]);
+        int rc = run_stage("hp stage", st, n_clips, ws, l.o_hp_state, d_changed, 4, d->t.max_passes,
+                           stream, &info[0], &info[3]);
         if (rc != OFP_OK) return rc;
     }
     OFP_HIP(hipEventRecord(ev[1], stream));
@@ -677,8 +867,8 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         st.L = l.ar_L;
         st.W = l.ar_W;
         st.n_chunks = l.ar_chunks;
-        int rc = run_stage("follower stage", st, n_clips, ws, l.o_ar_state, d_changed, d->t.max_passes,
-                           stream, &info[1], &info[3]);
+        int rc = run_stage("follower stage", st, n_clips, ws, l.o_ar_state, d_changed, 1,
+                           d->t.max_passes, stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
     OFP_HIP(hipEventRecord(ev[3], stream));
@@ -708,8 +898,8 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         st.L = l.mm_L;
         st.W = l.mm_W;
         st.n_chunks = l.mm_chunks;
-        int rc = run_stage("tracker stage", st, n_clips, ws, l.o_mm_state, d_changed, d->t.max_passes,
-                           stream, &info[2], &info[3]);
+        int rc = run_stage("tracker stage", st, n_clips, ws, l.o_mm_state, d_changed, 1,
+                           d->t.max_passes, stream, &info[2], &info[3]);
         if (rc != OFP_OK) return rc;
     }
 
@@ -745,7 +935,11 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sm.counts = d_counts;
     sm.clip_base = 0;
     {
-        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + 16;
+        const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
+        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)2 * tb * g.C * 4 + 16;
+        if (lds > 65536)
+            OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_state_machine),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
         OFP_LAUNCH_CHECK("k_state_machine");
     }
