@@ -100,6 +100,8 @@ typedef struct ofp_detect_tuning {
     int64_t ar_chunk, ar_warm;   /* follower stage */
     int64_t mm_chunk, mm_warm;   /* min/max tracker stage */
     int32_t max_passes;          /* repair passes before giving up (0: no limit) */
+    int64_t ar_coarse_warm;      /* follower stage: approximate-arithmetic warm-up that
+                                    produces the guess for the exact warm-up (<0: none) */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

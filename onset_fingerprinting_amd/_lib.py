@@ -49,6 +49,7 @@ class DetectTuning(ctypes.Structure):
         ("ar_chunk", ctypes.c_int64), ("ar_warm", ctypes.c_int64),
         ("mm_chunk", ctypes.c_int64), ("mm_warm", ctypes.c_int64),
         ("max_passes", ctypes.c_int32),
+        ("ar_coarse_warm", ctypes.c_int64),
     ]
 
 

@@ -89,7 +89,25 @@ struct HpStage {
         int64_t u = hp_dst(g, v);
         return u >= 0 ? out + (clip * g.U + u) * g.C + c : nullptr;
     }
-    __device__ float compute(State& s, float xv) const { return ofp_df2t4_step(xv, b, a, s.z); }
+    // ofp_df2t4_step with the same operations in the same order, arranged as 2-wide
+    // vectors so the compiler can use packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are
+    // per-lane IEEE fp32): pairs (z0,z2) and (z1,z3); the last tap adds -0.0f, which
+    // is exact for every addend including signed zeros.
+    __device__ float compute(State& s, float xv) const {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f B13 = {b[1], b[3]}, B24 = {b[2], b[4]}, A13 = {a[1], a[3]}, A24 = {a[2], a[4]};
+        v2f O = {s.z[1], s.z[3]};
+        v2f Wz = {s.z[2], -0.0f};
+        const float y = s.z[0] + b[0] * xv;
+        const v2f xx = {xv, xv}, yy = {y, y};
+        const v2f E2 = (O + B13 * xx) - A13 * yy;   // (z0', z2')
+        const v2f O2 = (Wz + B24 * xx) - A24 * yy;  // (z1', z3')
+        s.z[0] = E2.x;
+        s.z[2] = E2.y;
+        s.z[1] = O2.x;
+        s.z[3] = O2.y;
+        return y;
+    }
     __device__ Sparse sparse_begin(int64_t, int, int64_t) const { return Sparse{-1}; }
     __device__ void sparse_step(Sparse&, const State&) const {}
 };
@@ -105,13 +123,29 @@ struct ArStage {
     float* dif;        // [clips][U][C]
     float fa, fr, sa, sr, floor_db;
     int64_t L, W, n_chunks;
+    int64_t Wc;  // coarse (approximate-arithmetic) warm-up before the exact one
     __device__ int64_t len() const { return g.U; }
     __device__ int64_t brk(int) const { return 0; }
     __device__ State init(int64_t, int) const { return State{{floor_db, floor_db}}; }
-    __device__ State guess(int64_t clip, int c, int64_t u) const {
-        float v = *in_ptr(clip, c, u);
-        return State{{v, v}};
-    }
+    // Starting guess for the exact speculative warm-up at position u: the same
+    // followers run over the preceding Wc samples in plain fp32 fma arithmetic (a
+    // third of the instructions of the exact step).  Only a GUESS: exactness comes
+    // from the exact warm-up that follows plus the chunk-Jacobi verification.
+    struct Coarse {
+        static constexpr bool DENSE_OUT = false;
+        struct State { float z[2]; };
+        struct Sparse { int rem; };
+        Geom g;
+        float fa, fr, sa, sr;
+        __device__ float compute(State& s, float xv) const {
+            float d0 = xv - s.z[0], d1 = xv - s.z[1];
+            s.z[0] = fmaf(d0 > 0.0f ? fa : fr, d0, s.z[0]);
+            s.z[1] = fmaf(d1 > 0.0f ? sa : sr, d1, s.z[1]);
+            return 0.0f;
+        }
+        __device__ void sparse_step(Sparse&, const State&) const {}
+    };
+    __device__ State guess(int64_t clip, int c, int64_t u) const;
     __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return xdb + (clip * g.U + u) * g.C + c; }
     __device__ float* out_ptr(int64_t clip, int c, int64_t u) const { return dif + (clip * g.U + u) * g.C + c; }
     __device__ float compute(State& s, float xv) const {
@@ -148,9 +182,17 @@ struct MmStage {
     __device__ State guess(int64_t, int, int64_t) const { return State{{minmin, 0.f}}; }
     __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return rel + (clip * g.U + u) * g.C + c; }
     __device__ float* out_ptr(int64_t, int, int64_t) const { return nullptr; }
+    // ofp_min_step / ofp_max_step, same operations, the two EMAs as one 2-wide vector
     __device__ float compute(State& s, float xv) const {
-        s.z[0] = ofp_min_step(xv, s.z[0], ialpha_min, alpha_min, minmin);
-        s.z[1] = ofp_max_step(xv, s.z[1], ialpha_max, alpha_max);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f IA = {ialpha_min, ialpha_max}, AL = {alpha_min, alpha_max};
+        const v2f m = {s.z[0], s.z[1]}, xx = {xv, xv};
+        const v2f e = m * IA + xx * AL;
+        float mn = xv < s.z[0] ? xv : e.x;
+        mn = xv < minmin ? minmin : mn;
+        const float mx = xv > s.z[1] ? xv : e.y;
+        s.z[0] = mn;
+        s.z[1] = mx;
         return 0.0f;
     }
     __device__ Sparse sparse_begin(int64_t clip, int c, int64_t u) const {
@@ -245,6 +287,20 @@ __device__ __forceinline__ void run_affine_impl(const S& st, typename S::State& 
         if (HAS_OUT) { *op = o; op += stride; }
         if (SPARSE) st.sparse_step(sp, s);
     }
+}
+
+__device__ __forceinline__ ArStage::State ArStage::guess(int64_t clip, int c, int64_t u) const {
+    int64_t t0 = u - Wc;
+    Coarse cs{g, fa, fr, sa, sr};
+    Coarse::State s;
+    if (t0 <= 0) {
+        t0 = 0;
+        s.z[0] = s.z[1] = floor_db;  // the true initial state
+    } else {
+        s.z[0] = s.z[1] = *in_ptr(clip, c, t0);
+    }
+    if (u > t0) run_affine_impl<Coarse, false, false>(cs, s, in_ptr(clip, c, t0), nullptr, Coarse::Sparse{-1}, u - t0);
+    return State{{s.z[0], s.z[1]}};
 }
 
 template <class S, bool OUT>
@@ -623,7 +679,7 @@ struct Layout {
     Geom g;
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks;
-    int64_t ar_L, ar_W, ar_chunks;
+    int64_t ar_L, ar_W, ar_Wc, ar_chunks;
     int64_t mm_L, mm_W, mm_chunks;
     // byte offsets
     int64_t o_xdb, o_dif, o_hp_state, o_ar_state, o_mm_state, o_thr_mn, o_thr_mx, o_first,
@@ -648,7 +704,9 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // longest follower time constant in samples (coefficient = 1/samples)
     float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
     double tau = cmin > 0 ? 1.0 / cmin : 1.0;
-    int64_t ar_w_default = align_up((int64_t)std::min(20.0 * tau + 1024.0, 4.0e6), 1024);
+    int64_t ar_w_default = align_up((int64_t)std::min(8.0 * tau + 1024.0, 4.0e6), 1024);
+    l.ar_Wc = d->t.ar_coarse_warm > 0 ? d->t.ar_coarse_warm
+                                     : (d->t.ar_coarse_warm < 0 ? 0 : align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
     l.hp_L = pick(d->t.hp_chunk, 4096);
     l.hp_W = d->t.hp_warm > 0 ? d->t.hp_warm : (d->t.hp_warm < 0 ? 0 : 32768);
     l.ar_L = pick(d->t.ar_chunk, 4096);
@@ -866,6 +924,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         st.floor_db = p.floor_db;
         st.L = l.ar_L;
         st.W = l.ar_W;
+        st.Wc = l.ar_Wc;
         st.n_chunks = l.ar_chunks;
         int rc = run_stage("follower stage", st, n_clips, ws, l.o_ar_state, d_changed, 1,
                            d->t.max_passes, stream, &info[1], &info[3]);
