@@ -82,32 +82,19 @@ def main():
     pipe = FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local)
     frames_per_rank = C * pipe.n_frames(x.shape[0])
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     stage_acc = {}
 
     def step(timed):
-        s = torch.cuda.current_stream(dev)
-        out = pipe.detector.detect(xd, out=pipe._buffers(1, x.shape[0])["det"],
-                                   cap_per_clip=pipe._buffers(1, x.shape[0])["det"]["records"].shape[1])
-        b = pipe._bufs
-        ev[0].record(s)
-        from onset_fingerprinting_amd.data import stft_power_dense
-        power = stft_power_dense(xd, NFFT, HOP, out=b["power"])
-        ev[1].record(s)
-        mel = pipe.mel(power, out=b["mel"])
-        ev[2].record(s)
-        logits = pipe.classifier(mel.reshape(-1, NMELS))
-        ev[3].record(s)
+        out = pipe.run(xd, timed=timed)
         flat = flatten_records(out["records"], out["counts"], out["cap"], clip_offset=rank)
         gathered = all_gather_onsets(flat)
         if timed:
-            torch.cuda.synchronize(dev)
-            st = dict(pipe.detector.last_info["stage_ms"])
+            st = dict(out["info"]["stage_ms"])
             st.pop("total")
-            st.update(stft=ev[0].elapsed_time(ev[1]), mel=ev[1].elapsed_time(ev[2]), mlp=ev[2].elapsed_time(ev[3]))
+            st.update(out["spectral_ms"])  # runs concurrently with the detector on a second stream
             for k, v in st.items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
-        return out, power, mel, logits, gathered
+        return out, out["power"], out["mel"], out["logits"].reshape(-1, 8), gathered
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -102,6 +102,8 @@ typedef struct ofp_detect_tuning {
     int32_t max_passes;          /* repair passes before giving up (0: no limit) */
     int64_t ar_coarse_warm;      /* follower stage: approximate-arithmetic warm-up that
                                     produces the guess for the exact warm-up (<0: none) */
+    int64_t hp_candidates;       /* IIR stage: speculative candidates per chunk (default 8, max 16) */
+    int64_t hp_candidate_offset; /* IIR stage: samples between candidate starts (default 1021) */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -50,6 +50,8 @@ class DetectTuning(ctypes.Structure):
         ("mm_chunk", ctypes.c_int64), ("mm_warm", ctypes.c_int64),
         ("max_passes", ctypes.c_int32),
         ("ar_coarse_warm", ctypes.c_int64),
+        ("hp_candidates", ctypes.c_int64),
+        ("hp_candidate_offset", ctypes.c_int64),
     ]
 
 

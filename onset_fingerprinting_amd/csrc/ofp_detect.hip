@@ -179,7 +179,10 @@ struct MmStage {
     __device__ int64_t len() const { return g.U; }
     __device__ int64_t brk(int) const { return g.n_wb; }
     __device__ State init(int64_t, int) const { return State{{min0, max0}}; }
-    __device__ State guess(int64_t, int, int64_t) const { return State{{minmin, 0.f}}; }
+    // speculative start: the min from ABOVE (+inf: the first sample sets it; it coalesces with
+    // the true min at the first sample that resets the true one, which is frequent) and the max
+    // from BELOW (0: coalesces at the first sample that resets the true max)
+    __device__ State guess(int64_t, int, int64_t) const { return State{{__builtin_inff(), 0.f}}; }
     __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return rel + (clip * g.U + u) * g.C + c; }
     __device__ float* out_ptr(int64_t, int, int64_t) const { return nullptr; }
     // ofp_min_step / ofp_max_step, same operations, the two EMAs as one 2-wide vector
@@ -195,6 +198,22 @@ struct MmStage {
         s.z[1] = mx;
         return 0.0f;
     }
+    // max tracker only: the long part of the speculative warm-up exists for the max (it
+    // coalesces only at samples that reset it); the min snaps to `minmin` at every sample
+    // below it and needs only the short full-step tail of the warm-up.
+    struct MaxOnly {
+        static constexpr bool DENSE_OUT = false;
+        struct State { float z[1]; };
+        struct Sparse { int rem; };
+        Geom g;
+        float alpha_max, ialpha_max;
+        __device__ float compute(State& s, float xv) const {
+            s.z[0] = ofp_max_step(xv, s.z[0], ialpha_max, alpha_max);
+            return 0.0f;
+        }
+        __device__ void sparse_step(Sparse&, const State&) const {}
+    };
+    static constexpr int64_t WARM_FULL = 4096;
     __device__ Sparse sparse_begin(int64_t clip, int c, int64_t u) const {
         Sparse sp;
         sp.stride = g.C;
@@ -247,10 +266,9 @@ __device__ __forceinline__ void process_batch(const S& st, typename S::State& s,
     }
 }
 
-template <class S, bool HAS_OUT, bool SPARSE>
+template <class S, bool HAS_OUT, bool SPARSE, int PB = 16>
 __device__ __forceinline__ void run_affine_impl(const S& st, typename S::State& s, const float* ip, float* op,
                                                 typename S::Sparse sp, int64_t n) {
-    constexpr int PB = 16;
     const int64_t stride = st.g.C;
     float A[PB], Bv[PB];
     if (n >= PB) {
@@ -299,7 +317,7 @@ __device__ __forceinline__ ArStage::State ArStage::guess(int64_t clip, int c, in
     } else {
         s.z[0] = s.z[1] = *in_ptr(clip, c, t0);
     }
-    if (u > t0) run_affine_impl<Coarse, false, false>(cs, s, in_ptr(clip, c, t0), nullptr, Coarse::Sparse{-1}, u - t0);
+    if (u > t0) run_affine_impl<Coarse, false, false, 64>(cs, s, in_ptr(clip, c, t0), nullptr, Coarse::Sparse{-1}, u - t0);
     return State{{s.z[0], s.z[1]}};
 }
 
@@ -333,6 +351,27 @@ __device__ __forceinline__ void run_span(const S& st, typename S::State& s, int6
     }
 }
 
+// speculative warm-up over [ws, start): the exact step by default
+template <class S>
+__device__ __forceinline__ void warm_up(const S& st, typename S::State& s, int64_t clip, int c, int64_t ws,
+                                        int64_t start) {
+    run_span<S, false>(st, s, clip, c, ws, start);
+}
+template <>
+__device__ __forceinline__ void warm_up<MmStage>(const MmStage& st, MmStage::State& s, int64_t clip, int c,
+                                                 int64_t ws, int64_t start) {
+    const int64_t mid = max(ws, start - MmStage::WARM_FULL);
+    if (mid > ws && ws > 0) {  // (ws == 0 starts from the true state: run the full step throughout)
+        MmStage::MaxOnly mo{st.g, st.alpha_max, st.ialpha_max};
+        MmStage::MaxOnly::State ms{{s.z[1]}};
+        run_affine_impl<MmStage::MaxOnly, false, false, 64>(mo, ms, st.in_ptr(clip, c, ws), nullptr,
+                                                            MmStage::MaxOnly::Sparse{-1}, mid - ws);
+        s.z[1] = ms.z[0];
+        ws = mid;
+    }
+    run_span<MmStage, false>(st, s, clip, c, ws, start);
+}
+
 // One chunk-Jacobi pass.  Thread = (clip, chunk, channel), channel fastest.
 // State words are compared and stored as raw bits (NaN-safe).
 template <class S>
@@ -359,7 +398,7 @@ __global__ __launch_bounds__(64) void k_jacobi(S st, int pass, int64_t n_threads
         } else {
             s = st.guess(clip, c, ws);
         }
-        run_span<S, false>(st, s, clip, c, ws, start);
+        warm_up(st, s, clip, c, ws, start);
 #pragma unroll
         for (int i = 0; i < S::NS; ++i) used[sidx + i] = ofp_f2u(s.z[i]);
         run_span<S, true>(st, s, clip, c, start, end);
@@ -394,6 +433,379 @@ __global__ __launch_bounds__(64) void k_jacobi(S st, int pass, int64_t n_threads
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = ofp_f2u(s.z[i]);
     atomicAdd(changed, 1);
+}
+
+// ---- 4-lane form of the IIR stage ---------------------------------------------------
+// The IIR is the stage whose speculation rarely verifies (section 3 of DESIGN.md), so
+// its cost is (samples walked sequentially) x (time per step), and a lone wave issues one
+// instruction per 4 cycles.  Here FOUR lanes cooperate on one chain: lane k of a quad
+// owns delay z_k and the taps (b_{k+1}, a_{k+1}); z_0 and z_{k+1} arrive through DPP
+// quad permutes, so a step is ~9 instructions instead of ~22.  Lane k also loads
+// sample 4m+k and stores output 4m+k, i.e. one load and one store per four steps.
+// The operations and their order are those of ofp_df2t4_step (the last tap adds
+// -0.0f, exact for every addend), so results are bit-identical.
+template <int CTRL>
+__device__ __forceinline__ float qperm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+struct Hp4 {
+    float z, Bk, Ak, b0;
+    bool last;  // lane 3 of the quad
+};
+
+__device__ __forceinline__ float hp4_step(float x, Hp4& h) {
+    const float bx = h.Bk * x;
+    const float y = qperm<0x00>(h.z) + h.b0 * x;  // z0 of the quad
+    float zn = qperm<0xF9>(h.z);                   // z_{k+1}
+    zn = h.last ? -0.0f : zn;
+    const float t = zn + bx;
+    h.z = t - h.Ak * y;
+    return y;
+}
+
+template <bool HAS_OUT>
+__device__ __forceinline__ void hp4_quad_block(float xr, Hp4& h, int k4, float* opl) {
+    const float y0 = hp4_step(qperm<0x00>(xr), h);
+    const float y1 = hp4_step(qperm<0x55>(xr), h);
+    const float y2 = hp4_step(qperm<0xAA>(xr), h);
+    const float y3 = hp4_step(qperm<0xFF>(xr), h);
+    if (HAS_OUT) {
+        float yk = k4 == 0 ? y0 : y1;
+        yk = k4 == 2 ? y2 : yk;
+        yk = k4 == 3 ? y3 : yk;
+        *opl = yk;
+    }
+}
+
+// positions [t0, t1) of an affine span (addresses affine in the position)
+template <bool HAS_OUT>
+__device__ __forceinline__ void hp4_affine(Hp4& h, int k4, const float* ip, float* op, int64_t stride, int64_t n) {
+    constexpr int PB = 8;  // registers of prefetch = 4*PB steps
+    const float* ipl = ip + k4 * stride;
+    float* opl = HAS_OUT ? op + k4 * stride : nullptr;
+    const int64_t s4 = 4 * stride;
+    int64_t nb = n >> 2;  // blocks of four steps
+    float A[PB], Bv[PB];
+    if (nb >= PB) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) A[i] = ipl[i * s4];
+        ipl += PB * s4;
+        nb -= PB;
+        while (nb >= 2 * PB) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) Bv[i] = ipl[i * s4];
+            ipl += PB * s4;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(A[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
+            if (HAS_OUT) opl += PB * s4;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) A[i] = ipl[i * s4];
+            ipl += PB * s4;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(Bv[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
+            if (HAS_OUT) opl += PB * s4;
+            nb -= 2 * PB;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(A[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
+        if (HAS_OUT) opl += PB * s4;
+    }
+    for (; nb > 0; --nb) {
+        hp4_quad_block<HAS_OUT>(*ipl, h, k4, opl);
+        ipl += s4;
+        if (HAS_OUT) opl += s4;
+    }
+    // fewer than four steps left: every lane reads the same sample, lane 0 stores
+    const float* ipr = ipl - k4 * stride;
+    float* opr = HAS_OUT ? opl - k4 * stride : nullptr;
+    for (int r = (int)(n & 3); r > 0; --r) {
+        const float y = hp4_step(*ipr, h);
+        ipr += stride;
+        if (HAS_OUT) {
+            if (k4 == 0) *opr = y;
+            opr += stride;
+        }
+    }
+}
+
+template <bool OUT>
+__device__ __forceinline__ void hp4_span(const HpStage& st, Hp4& h, int k4, int64_t clip, int c, int64_t t0,
+                                         int64_t t1) {
+    int64_t a = t0;
+#pragma unroll
+    for (int i = 0; i <= HpStage::NBRK; ++i) {
+        int64_t b = t1;
+        if (i < HpStage::NBRK) b = min(max(st.brk(i), a), t1);
+        if (b > a) {
+            const float* ip = st.in_ptr(clip, c, a);
+            float* op = OUT ? st.out_ptr(clip, c, a) : nullptr;
+            if (op) hp4_affine<true>(h, k4, ip, op, st.g.C, b - a);
+            else hp4_affine<false>(h, k4, ip, nullptr, st.g.C, b - a);
+        }
+        a = b;
+    }
+}
+
+// chunk-Jacobi pass, thread = (clip, chunk, channel, delay k4); same protocol as k_jacobi
+__global__ __launch_bounds__(64) void k_jacobi_hp4(HpStage st, int pass, int64_t n_threads,
+                                                   const uint32_t* __restrict__ end_prev,
+                                                   uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                   int* changed) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;  // n_threads is a multiple of 4: quads are never split
+    const int k4 = (int)(id & 3);
+    const int64_t q = id >> 2;
+    const int C = st.g.C;
+    const int c = (int)(q % C);
+    const int64_t r = q / C;
+    const int64_t k = r % st.n_chunks;
+    const int64_t clip = r / st.n_chunks;
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.len());
+    const int64_t sidx = ((clip * st.n_chunks + k) * C + c) * 4 + k4;
+    Hp4 h;
+    h.Bk = st.b[k4 + 1];
+    h.Ak = st.a[k4 + 1];
+    h.b0 = st.b[0];
+    h.last = k4 == 3;
+    if (pass == 0) {
+        int64_t ws = max<int64_t>(start - st.W, 0);
+        h.z = 0.0f;  // true initial state at 0, guess elsewhere
+        hp4_span<false>(st, h, k4, clip, c, ws, start);
+        used[sidx] = ofp_f2u(h.z);
+        hp4_span<true>(st, h, k4, clip, c, start, end);
+        end_next[sidx] = ofp_f2u(h.z);
+        return;
+    }
+    if (k == 0) {
+        end_next[sidx] = end_prev[sidx];
+        return;
+    }
+    const uint32_t in = end_prev[sidx - (int64_t)C * 4];
+    const bool diff = in != used[sidx];
+    // the four lanes of a quad decide together (any delay differs -> re-run the chain)
+    unsigned long long m = __ballot(diff);
+    const int lane = threadIdx.x & 63;
+    const bool rerun = ((m >> (lane & ~3)) & 0xfull) != 0ull;
+    if (!rerun) {
+        end_next[sidx] = end_prev[sidx];
+        return;
+    }
+    h.z = ofp_u2f(in);
+    used[sidx] = in;
+    hp4_span<true>(st, h, k4, clip, c, start, end);
+    end_next[sidx] = ofp_f2u(h.z);
+    if (k4 == 0) atomicAdd(changed, 1);
+}
+
+// ---- IIR stage, multi-candidate speculation ------------------------------------------
+// A single speculative warm-up coalesces with the true trajectory only at loud events
+// and only with probability ~1/2 per event, so chunk-Jacobi on the IIR walks long
+// stretches sequentially.  Instead every chunk start gets R candidate states, from R
+// speculative runs that begin at different offsets (different rounding histories = R
+// independent chances to coalesce), each continued to the chunk end:
+//     U[k][r] = candidate state at the start of chunk k,  E[k][r] = state at its end.
+// Resolution then walks each chain: the true start of chunk k is E[k-1][sel[k-1]];
+// if some U[k][r] equals it bitwise, sel[k] = r and the walk continues for free,
+// otherwise chunk k is run once from the true state (slot R) and the walk resumes.
+// Finally every chunk is run from its verified start state and writes the output.
+// Only bitwise-verified states are ever used, so the result is the sequential one.
+constexpr int HP_MAXR = 16;
+
+struct HpCand {
+    HpStage st;
+    int R;            // candidates per chunk (slots 0..R-1; slot R = exact re-run)
+    int64_t delta;    // offset between candidate starts
+    uint32_t* U;      // [clips][chunks][C][R+1][4]
+    uint32_t* E;      // same shape
+    int8_t* sel;      // [clips][chunks][C] chosen slot, -1 unknown
+    uint8_t* done;    // [clips][chunks][C] output written
+    uint8_t* nxt;     // [clips][chunks][C][R+1] slot of chunk k matching E[k-1][r], 255 none
+    int* counters;    // [0] chains with an unresolved chunk after the last resolve
+    int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
+    __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
+        return ((((clip * st.n_chunks + k) * st.g.C + c) * (R + 1)) + r) * 4;
+    }
+};
+
+// pass A: thread = (clip, chunk, channel, candidate, delay)
+__global__ __launch_bounds__(64) void k_hp_candidates(HpCand a, int64_t n_threads) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const HpStage& st = a.st;
+    const int k4 = (int)(id & 3);
+    int64_t q = id >> 2;
+    const int r = (int)(q % a.R);
+    q /= a.R;
+    const int C = st.g.C;
+    const int c = (int)(q % C);
+    q /= C;
+    const int64_t k = q % st.n_chunks;
+    const int64_t clip = q / st.n_chunks;
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.len());
+    const int64_t si = a.slot(clip, k, c, r) + k4;
+    if (k4 == 0 && r == 0) {
+        a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
+        a.done[(clip * st.n_chunks + k) * C + c] = 0;
+        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
+    }
+    Hp4 h;
+    h.Bk = st.b[k4 + 1];
+    h.Ak = st.a[k4 + 1];
+    h.b0 = st.b[0];
+    h.last = k4 == 3;
+    h.z = 0.0f;
+    const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
+    hp4_span<false>(st, h, k4, clip, c, ws, start);
+    a.U[si] = ofp_f2u(h.z);
+    hp4_span<false>(st, h, k4, clip, c, start, end);
+    a.E[si] = ofp_f2u(h.z);
+}
+
+// pass A, one lane per candidate (packed-fp32 step of HpStage::compute): four times
+// fewer lanes than the quad form, which matters here because EVERY candidate of every
+// chunk runs (thousands of waves); the quad form is kept for the sparse re-runs.
+__global__ __launch_bounds__(64) void k_hp_candidates1(HpCand a, int64_t n_threads) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const HpStage& st = a.st;
+    int64_t q = id;
+    const int C = st.g.C;
+    const int c = (int)(q % C);
+    q /= C;
+    const int r = (int)(q % a.R);   // candidates of one chunk sit in different waves' lanes: same trip count per lane group
+    q /= a.R;
+    const int64_t k = q % st.n_chunks;
+    const int64_t clip = q / st.n_chunks;
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.len());
+    const int64_t si = a.slot(clip, k, c, r);
+    if (r == 0) {
+        a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
+        a.done[(clip * st.n_chunks + k) * C + c] = 0;
+        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty
+    }
+    HpStage::State s = st.init(clip, c);
+    const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
+    run_span<HpStage, false>(st, s, clip, c, ws, start);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.U[si + i] = ofp_f2u(s.z[i]);
+    run_span<HpStage, false>(st, s, clip, c, start, end);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.E[si + i] = ofp_f2u(s.z[i]);
+}
+
+// pass B1: nxt[k][c][r_prev] for every chunk k >= 1 (parallel)
+__global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_items) return;
+    const int R1 = a.R + 1;
+    const int rp = (int)(id % R1);
+    int64_t q = id / R1;
+    const int C = a.st.g.C;
+    const int c = (int)(q % C);
+    q /= C;
+    const int64_t k = q % a.st.n_chunks;
+    const int64_t clip = q / a.st.n_chunks;
+    uint8_t res = 255;
+    if (k > 0) {
+        const uint32_t* e = a.E + a.slot(clip, k - 1, c, rp);
+        const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+        for (int r = 0; r < R1; ++r) {
+            const uint32_t* u = a.U + a.slot(clip, k, c, r);
+            if (u[0] == e0 && u[1] == e1 && u[2] == e2 && u[3] == e3) {
+                res = (uint8_t)r;
+                break;
+            }
+        }
+    }
+    a.nxt[id] = res;
+}
+
+// pass B2: one wave per chain walks the match table (staged through LDS in tiles)
+__global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
+    __shared__ uint8_t tile[64 * (HP_MAXR + 1)];
+    const int C = a.st.g.C, R1 = a.R + 1;
+    const int64_t chain = blockIdx.x;  // clip*C + c
+    const int c = (int)(chain % C);
+    const int64_t clip = chain / C;
+    const int64_t nk = a.st.n_chunks;
+    const int lane = threadIdx.x;
+    // resume where the previous round stopped: chunks before pos[] are resolved
+    const int64_t kstart = max<int64_t>(1, a.pos[chain]);
+    int cur = a.sel[(clip * nk + kstart - 1) * C + c];  // slot chosen for the previous chunk
+    bool stuck = false;
+    int64_t reached = nk;
+    for (int64_t k0 = kstart; k0 < nk && !stuck; k0 += 64) {
+        const int nblk = (int)min<int64_t>(64, nk - k0);
+        __syncthreads();
+        for (int i = lane; i < nblk * R1; i += 64) {
+            const int bk = i / R1, r = i % R1;
+            tile[i] = a.nxt[(((clip * nk + k0 + bk) * C + c) * R1) + r];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int bk = 0; bk < nblk; ++bk) {
+                int8_t* sp = a.sel + (clip * nk + k0 + bk) * C + c;
+                int s = *sp;
+                if (s < 0) {
+                    const uint8_t m = tile[bk * R1 + cur];
+                    if (m == 255) { stuck = true; reached = k0 + bk; break; }
+                    s = m;
+                    *sp = (int8_t)s;
+                }
+                cur = s;
+            }
+        }
+        stuck = __shfl(stuck ? 1 : 0, 0) != 0;
+    }
+    if (lane == 0) {
+        a.pos[chain] = (int32_t)reached;
+        if (stuck) atomicAdd(a.counters, 1);
+    }
+}
+
+// pass C: run every chunk whose true start state is known and that has not produced its
+// output yet, from that state; a chunk without a matching candidate fills slot R.
+__global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const HpStage& st = a.st;
+    const int k4 = (int)(id & 3);
+    int64_t q = id >> 2;
+    const int C = st.g.C;
+    const int c = (int)(q % C);
+    q /= C;
+    const int64_t k = q % st.n_chunks;
+    const int64_t clip = q / st.n_chunks;
+    const int64_t ci = (clip * st.n_chunks + k) * C + c;
+    if (a.done[ci]) return;
+    int sp = 0;
+    if (k > 0) {
+        sp = a.sel[ci - C];
+        if (sp < 0) return;  // predecessor not resolved yet
+    }
+    Hp4 h;
+    h.Bk = st.b[k4 + 1];
+    h.Ak = st.a[k4 + 1];
+    h.b0 = st.b[0];
+    h.last = k4 == 3;
+    const uint32_t xin = (k == 0) ? 0u : a.E[a.slot(clip, k - 1, c, sp) + k4];
+    h.z = ofp_u2f(xin);
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.len());
+    hp4_span<true>(st, h, k4, clip, c, start, end);
+    const bool unresolved = a.sel[ci] < 0;
+    if (unresolved) {
+        a.U[a.slot(clip, k, c, a.R) + k4] = xin;
+        a.E[a.slot(clip, k, c, a.R) + k4] = ofp_f2u(h.z);
+    }
+    // sel[ci] is NOT written here: a successor chunk running in this same launch must not
+    // see a slot that is still being filled.  The next k_hp_match finds slot R (its U equals
+    // the predecessor's end state by construction) and k_hp_resolve then selects it.
+    if (k4 == 0) a.done[ci] = 1;  // the four lanes read done[] above, before this write (one wave, in order)
 }
 
 // ---- elementwise stages ----------------------------------------------------
@@ -678,7 +1090,9 @@ __global__ __launch_bounds__(64) void k_backtrack(BtArgs a) {
 struct Layout {
     Geom g;
     int64_t nb;
-    int64_t hp_L, hp_W, hp_chunks;
+    int64_t hp_L, hp_W, hp_chunks, hp_delta;
+    int hp_R;
+    int64_t o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_pos;
     int64_t ar_L, ar_W, ar_Wc, ar_chunks;
     int64_t mm_L, mm_W, mm_chunks;
     // byte offsets
@@ -704,15 +1118,17 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // longest follower time constant in samples (coefficient = 1/samples)
     float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
     double tau = cmin > 0 ? 1.0 / cmin : 1.0;
-    int64_t ar_w_default = align_up((int64_t)std::min(8.0 * tau + 1024.0, 4.0e6), 1024);
+    int64_t ar_w_default = align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024);
     l.ar_Wc = d->t.ar_coarse_warm > 0 ? d->t.ar_coarse_warm
                                      : (d->t.ar_coarse_warm < 0 ? 0 : align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
-    l.hp_L = pick(d->t.hp_chunk, 4096);
-    l.hp_W = d->t.hp_warm > 0 ? d->t.hp_warm : (d->t.hp_warm < 0 ? 0 : 32768);
+    l.hp_L = pick(d->t.hp_chunk, 8192);
+    l.hp_W = d->t.hp_warm > 0 ? d->t.hp_warm : (d->t.hp_warm < 0 ? 0 : 49152);
+    l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, 8)));
+    l.hp_delta = pick(d->t.hp_candidate_offset, 1021);
     l.ar_L = pick(d->t.ar_chunk, 4096);
     l.ar_W = d->t.ar_warm > 0 ? d->t.ar_warm : (d->t.ar_warm < 0 ? 0 : ar_w_default);
     l.mm_L = pick(d->t.mm_chunk, 8192);
-    l.mm_W = d->t.mm_warm > 0 ? d->t.mm_warm : (d->t.mm_warm < 0 ? 0 : 98304);
+    l.mm_W = d->t.mm_warm > 0 ? d->t.mm_warm : (d->t.mm_warm < 0 ? 0 : 49152);
     l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
     l.ar_chunks = std::max<int64_t>(1, cdiv(g.U, l.ar_L));
     l.mm_chunks = std::max<int64_t>(1, cdiv(g.U, l.mm_L));
@@ -725,7 +1141,16 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     const int64_t stream = n_clips * g.U * g.C * 4;
     l.o_xdb = take(stream);
     l.o_dif = take(stream);
-    l.o_hp_state = take(3 * n_clips * l.hp_chunks * g.C * 4 * 4);
+    l.o_hp_state = take(256);
+    {
+        const int64_t cc = n_clips * l.hp_chunks * g.C;
+        l.o_hp_U = take(cc * (l.hp_R + 1) * 16);
+        l.o_hp_E = take(cc * (l.hp_R + 1) * 16);
+        l.o_hp_sel = take(cc);
+        l.o_hp_done = take(cc);
+        l.o_hp_nxt = take(cc * (l.hp_R + 1));
+        l.o_hp_pos = take(n_clips * g.C * 4);
+    }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
     l.o_mm_state = take(3 * n_clips * l.mm_chunks * g.C * 2 * 4);
     l.o_thr_mn = take(n_clips * l.nb * g.C * 4);
@@ -744,6 +1169,16 @@ int launch_pass(const char* name, const S& st, int pass, int64_t n_threads, cons
     const unsigned grid = (unsigned)cdiv(n_threads, 64);
     hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(64), 0, stream, st, pass, n_threads, prev, next, used,
                        d_changed);
+    OFP_LAUNCH_CHECK(name);
+    return OFP_OK;
+}
+
+template <>
+int launch_pass<HpStage>(const char* name, const HpStage& st, int pass, int64_t n_threads, const uint32_t* prev,
+                         uint32_t* next, uint32_t* used, int* d_changed, hipStream_t stream) {
+    const int64_t n4 = n_threads * 4;  // four lanes per chain
+    hipLaunchKernelGGL(k_jacobi_hp4, dim3((unsigned)cdiv(n4, 64)), dim3(64), 0, stream, st, pass, n4, prev, next,
+                       used, d_changed);
     OFP_LAUNCH_CHECK(name);
     return OFP_OK;
 }
@@ -901,9 +1336,41 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         st.L = l.hp_L;
         st.W = l.hp_W;
         st.n_chunks = l.hp_chunks;
-        int rc = run_stage("hp stage", st, n_clips, ws, l.o_hp_state, d_changed, 4, d->t.max_passes,
-                           stream, &info[0], &info[3]);
-        if (rc != OFP_OK) return rc;
+        HpCand hc;
+        hc.st = st;
+        hc.R = l.hp_R;
+        hc.delta = l.hp_delta;
+        hc.U = reinterpret_cast<uint32_t*>(ws + l.o_hp_U);
+        hc.E = reinterpret_cast<uint32_t*>(ws + l.o_hp_E);
+        hc.sel = reinterpret_cast<int8_t*>(ws + l.o_hp_sel);
+        hc.done = reinterpret_cast<uint8_t*>(ws + l.o_hp_done);
+        hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
+        hc.counters = d_changed;
+        hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
+        OFP_HIP(hipMemsetAsync(hc.pos, 0, n_clips * g.C * 4, stream));
+        const int64_t chains = n_clips * g.C;
+        const int64_t nA = n_clips * l.hp_chunks * g.C * hc.R * 4;
+        const int64_t nM = n_clips * l.hp_chunks * g.C * (hc.R + 1);
+        const int64_t nC = n_clips * l.hp_chunks * g.C * 4;
+        hipLaunchKernelGGL(k_hp_candidates1, dim3((unsigned)cdiv(nA / 4, 64)), dim3(64), 0, stream, hc, nA / 4);
+        OFP_LAUNCH_CHECK("k_hp_candidates1");
+        for (int it = 0;; ++it) {
+            OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
+            OFP_LAUNCH_CHECK("k_hp_match");
+            hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
+            OFP_LAUNCH_CHECK("k_hp_resolve");
+            int stuck = 0;
+            OFP_HIP(hipMemcpyAsync(&stuck, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
+            OFP_LAUNCH_CHECK("k_hp_run");
+            OFP_HIP(hipStreamSynchronize(stream));
+            info[0] += 1;
+            info[3] += stuck;
+            if (stuck == 0) break;
+            if (d->t.max_passes > 0 && it >= d->t.max_passes)
+                return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
+        }
     }
     OFP_HIP(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, d_x, xdb, n_clips,

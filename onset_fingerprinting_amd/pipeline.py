@@ -47,6 +47,7 @@ class FingerprintPipeline:
         self.mel = MelBank(sr, n_fft, n_mels, device=device)
         self.classifier = classifier if classifier is not None else seeded_fcnn(n_mels, 8)
         self._bufs = None
+        self._side = None
 
     def n_frames(self, n_samples):
         return 0 if n_samples < self.n_fft else 1 + (n_samples - self.n_fft) // self.hop
@@ -68,14 +69,36 @@ class FingerprintPipeline:
             self.detector.reserve(n_clips, N, int(0.5 * self.sr))
         return self._bufs
 
-    def run(self, x):
-        """x float32 CUDA [n_clips, N, C] -> dict(records, counts, cap, rel, power, mel, logits)."""
+    def run(self, x, timed=False):
+        """x float32 CUDA [n_clips, N, C] -> dict(records, counts, cap, rel, power, mel, logits).
+
+        The spectral branch (rFFT -> mel -> classifier) does not depend on the detector, and the
+        detector is a latency-bound recurrence that occupies a small part of the chip, so the two
+        branches run concurrently on two HIP streams and join at the end."""
         n_clips, N, C = x.shape
         b = self._buffers(n_clips, N)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._ev[0].record(side)
+            power = stft_power_dense(x, self.n_fft, self.hop, out=b["power"])
+            self._ev[1].record(side)
+            mel = self.mel(power, out=b["mel"])
+            self._ev[2].record(side)
+            logits = self.classifier(mel.reshape(-1, self.n_mels))
+            self._ev[3].record(side)
         det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1])
-        power = stft_power_dense(x, self.n_fft, self.hop, out=b["power"])
-        mel = self.mel(power, out=b["mel"])
-        logits = self.classifier(mel.reshape(-1, self.n_mels))
-        return dict(records=det["records"], counts=det["counts"], cap=det["cap"], rel=det["rel"], power=power,
-                    mel=mel, logits=logits.reshape(n_clips, C, -1, logits.shape[-1]),
-                    info=self.detector.last_info)
+        main.wait_stream(side)
+        out = dict(records=det["records"], counts=det["counts"], cap=det["cap"], rel=det["rel"], power=power,
+                   mel=mel, logits=logits.reshape(n_clips, C, -1, logits.shape[-1]),
+                   info=self.detector.last_info)
+        if timed:
+            torch.cuda.synchronize(self.device)
+            e = self._ev
+            out["spectral_ms"] = dict(stft=e[0].elapsed_time(e[1]), mel=e[1].elapsed_time(e[2]),
+                                      mlp=e[2].elapsed_time(e[3]))
+        return out
