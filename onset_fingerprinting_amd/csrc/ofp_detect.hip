@@ -4,20 +4,26 @@
 // envelope_follower.c (followers / tracker / backtracking).  The arithmetic of
 // every step is the single definition in include/ofp_math.h.
 //
-// How a sequential recurrence is made time-parallel WITHOUT changing a bit
-// ("chunk-Jacobi"): the stream of one chain (clip x channel) is cut into chunks;
-// pass 0 runs every chunk from a guessed state after a speculative warm-up of W
-// samples and records the state it actually started the chunk from (`used`) and
-// the state it ended with (`end`).  Pass j >= 1 re-runs exactly those chunks whose
-// recorded start state differs (bitwise) from the end state of the preceding
-// chunk, starting from that end state.  Chunk 0 always starts from the true
-// initial state, so by induction the fixed point of this iteration IS the
-// sequential result; the host stops when a pass changes nothing.  With an
-// adequate warm-up the common case is pass 0 + one verification pass that only
-// compares states.  The worst case degenerates to sequential speed, never to a
-// wrong answer.
+// The detector is a chain of sequential recurrences along time; a lone wave retires one
+// dependent VALU operation per ~9 cycles, so one chain costs 11-40 ns per sample and the
+// parallelism has to come from cutting time into chunks WITHOUT changing a bit:
 //
-// Stages (each its own chunk-Jacobi loop, in stream order):
+//  * chunk-Jacobi (followers, tracker): pass 0 runs every chunk from a guessed state
+//    after a speculative warm-up and records the state it USED at the chunk start and
+//    the state it ENDED with; pass j >= 1 re-runs exactly the chunks whose used state
+//    differs bitwise from the end state of the preceding chunk.  Chunk 0 starts from
+//    the true state, so the fixed point IS the sequential result; the host stops when
+//    a pass changes nothing.  Worst case: sequential speed, never a wrong answer.
+//  * multi-candidate speculation (the IIR, whose trajectories coalesce only at loud
+//    events): see the block comment above k_hp_candidates.
+//
+// Data layout: every internal stream is PLANAR, one contiguous fp32 series per chain
+// ([clip][channel][time]), so a lane walks its own series with 16-byte loads and the
+// register prefetch covers 64+ steps of memory latency.  The caller's interleaved
+// [time][channel] audio is transposed once on entry (k_transpose_in) and the relative
+// envelope once on exit (k_rel_out).
+//
+// Stages, in stream order:
 //   hp : 4th-order high-pass IIR (detection.py:743-744)      state z[4]
 //   db : rectified dB with floor (detection.py:747-748)      elementwise
 //   ar : fast & slow attack/release followers (:751)         state (yf, ys)
@@ -41,6 +47,8 @@ namespace {
 using ofp::align_up;
 using ofp::cdiv;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------
 // stream geometry of one clip (all in samples)
 struct Geom {
@@ -52,7 +60,8 @@ struct Geom {
     int64_t V;     // high-pass stream length n_w + Nm
     int32_t C, B;
 };
-
+// The reference processes x[0:n_w] (init_minmax_tracker) and then restarts at x[0] with all
+// filter/follower/tracker state kept.  hp stream position v -> audio index / follower index:
 __host__ __device__ inline int64_t hp_src(const Geom& g, int64_t v) { return v < g.n_w ? v : v - g.n_w; }
 __host__ __device__ inline int64_t hp_dst(const Geom& g, int64_t v) {
     return v < g.n_wb ? v : (v >= g.n_w ? v - g.n_w + g.n_wb : -1);
@@ -60,561 +69,460 @@ __host__ __device__ inline int64_t hp_dst(const Geom& g, int64_t v) {
 __host__ __device__ inline int64_t u_src(const Geom& g, int64_t u) { return u < g.n_wb ? u : u - g.n_wb; }
 
 // ---------------------------------------------------------------------------
-// stages.  Each stage describes one sequential recurrence over a stream:
-//   NS / State      the carried state words
-//   NBRK / brk(i)   stream positions where the stream<->memory mapping changes
-//                   (between two breaks input and output addresses are affine in
-//                   the position, so the inner loop only increments pointers)
-//   in_ptr/out_ptr  address of element (clip, c, pos); out_ptr may be null
-//   compute         one step (include/ofp_math.h), returns the dense output value
-struct HpStage {
-    static constexpr int NS = 4;
-    static constexpr int NBRK = 2;
-    static constexpr bool DENSE_OUT = true;
-    struct State { float z[4]; };
-    struct Sparse { int rem; };
-    Geom g;
-    const float* x;  // [clips][N][C]
-    float* out;      // [clips][U][C]
-    float b[5], a[5];
-    int64_t L, W, n_chunks;
-    __device__ int64_t len() const { return g.V; }
-    __device__ int64_t brk(int i) const { return i == 0 ? g.n_wb : g.n_w; }
-    __device__ State init(int64_t, int) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
-    __device__ State guess(int64_t, int, int64_t) const { return State{{0.f, 0.f, 0.f, 0.f}}; }
-    __device__ const float* in_ptr(int64_t clip, int c, int64_t v) const {
-        return x + (clip * g.N + hp_src(g, v)) * g.C + c;
+// walk: the one inner loop.  A lane walks n consecutive floats of ITS OWN series,
+// applying a step functor; inputs arrive through 16-byte loads issued a whole batch
+// (4*PB4 steps) ahead into a ping-pong pair of register sets, because their addresses do
+// not depend on the recurrence.  OUT: 0 none, 1 scalar stores, 4 16-byte stores (op must
+// then be congruent to ip modulo 16 bytes).  EV: the functor wants a per-step event
+// (`rem` counts steps to the next event; rem < 0 disables) -- used by the tracker to
+// emit its state at block ends without a per-step branch in the common batch.
+template <int PB4, int OUT, bool EV, bool DEEP = false, class F>
+__device__ __forceinline__ void walk(const float* ip, float* op, int64_t n, int& rem, F& f) {
+    auto one = [&](float x) {
+        float o = f(x);
+        if (OUT) *op++ = o;
+        if (EV && rem >= 0) {
+            if (rem == 0) f.event();
+            rem -= 1;
+        }
+    };
+    while (n > 0 && (reinterpret_cast<uintptr_t>(ip) & 15u)) {
+        one(*ip++);
+        --n;
     }
-    __device__ float* out_ptr(int64_t clip, int c, int64_t v) const {
-        int64_t u = hp_dst(g, v);
-        return u >= 0 ? out + (clip * g.U + u) * g.C + c : nullptr;
+    const float4* q = reinterpret_cast<const float4*>(ip);
+    int64_t nb = n >> 2;
+    auto batch = [&](const float4 (&v)[PB4]) {
+        if (EV && rem >= 0 && rem < 4 * PB4) {  // an event falls inside this batch (rare)
+#pragma unroll
+            for (int i = 0; i < PB4; ++i) {
+                one(v[i].x); one(v[i].y); one(v[i].z); one(v[i].w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PB4; ++i) {
+                float4 o;
+                o.x = f(v[i].x); o.y = f(v[i].y); o.z = f(v[i].z); o.w = f(v[i].w);
+                if (OUT == 4) reinterpret_cast<float4*>(op)[i] = o;
+                if (OUT == 1) { op[4 * i] = o.x; op[4 * i + 1] = o.y; op[4 * i + 2] = o.z; op[4 * i + 3] = o.w; }
+            }
+            if (OUT) op += 4 * PB4;
+            if (EV && rem >= 0) rem -= 4 * PB4;
+        }
+    };
+    auto load = [&](float4 (&v)[PB4]) {
+#pragma unroll
+        for (int i = 0; i < PB4; ++i) v[i] = q[i];
+        q += PB4;
+        // keep the whole group issued here: hipcc otherwise sinks each load next to its use
+        // and exposes one memory latency per few steps instead of one per batch
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](const float4 (&v)[PB4]) {
+        batch(v);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (DEEP) {
+        // three register sets: two batches of loads are in flight while the third is consumed
+        // (for the light steps, whose batch is shorter than one HBM round trip)
+        float4 A[PB4], Bv[PB4], Cv[PB4];
+        if (nb >= 2 * PB4) {
+            load(A);
+            load(Bv);
+            nb -= 2 * PB4;
+            while (nb >= 3 * PB4) {
+                load(Cv); run(A);
+                load(A); run(Bv);
+                load(Bv); run(Cv);
+                nb -= 3 * PB4;
+            }
+            run(A);
+            run(Bv);
+        }
+    } else {
+        float4 A[PB4], Bv[PB4];
+        if (nb >= PB4) {
+            load(A);
+            nb -= PB4;
+            while (nb >= 2 * PB4) {
+                load(Bv); run(A);
+                load(A); run(Bv);
+                nb -= 2 * PB4;
+            }
+            run(A);
+        }
     }
-    // ofp_df2t4_step with the same operations in the same order, arranged as 2-wide
-    // vectors so the compiler can use packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are
-    // per-lane IEEE fp32): pairs (z0,z2) and (z1,z3); the last tap adds -0.0f, which
-    // is exact for every addend including signed zeros.
-    __device__ float compute(State& s, float xv) const {
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f B13 = {b[1], b[3]}, B24 = {b[2], b[4]}, A13 = {a[1], a[3]}, A24 = {a[2], a[4]};
-        v2f O = {s.z[1], s.z[3]};
-        v2f Wz = {s.z[2], -0.0f};
-        const float y = s.z[0] + b[0] * xv;
+    while (nb > 0) {  // leftover whole float4s
+        const float4 v = *q++;
+        one(v.x); one(v.y); one(v.z); one(v.w);
+        --nb;
+    }
+    ip = reinterpret_cast<const float*>(q);
+    for (int r = (int)(n & 3); r > 0; --r) one(*ip++);
+}
+
+// ---------------------------------------------------------------------------
+// step functors (state by value inside; include/ofp_math.h is the definition)
+
+// ofp_df2t4_step with the same operations in the same order, arranged as 2-wide vectors so
+// the compiler can use packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are per-lane IEEE fp32):
+// pairs (z0,z2) and (z1,z3); the last tap adds -0.0f, exact for every addend.
+struct HpStep {
+    float z[4];
+    float b0;
+    v2f B13, B24, A13, A24;
+    __device__ void coeffs(const float* b, const float* a) {
+        b0 = b[0];
+        B13 = v2f{b[1], b[3]}; B24 = v2f{b[2], b[4]};
+        A13 = v2f{a[1], a[3]}; A24 = v2f{a[2], a[4]};
+    }
+    __device__ float operator()(float xv) {
+        v2f O = {z[1], z[3]};
+        v2f Wz = {z[2], -0.0f};
+        const float y = z[0] + b0 * xv;
         const v2f xx = {xv, xv}, yy = {y, y};
         const v2f E2 = (O + B13 * xx) - A13 * yy;   // (z0', z2')
         const v2f O2 = (Wz + B24 * xx) - A24 * yy;  // (z1', z3')
-        s.z[0] = E2.x;
-        s.z[2] = E2.y;
-        s.z[1] = O2.x;
-        s.z[3] = O2.y;
+        z[0] = E2.x; z[2] = E2.y; z[1] = O2.x; z[3] = O2.y;
         return y;
     }
-    __device__ Sparse sparse_begin(int64_t, int, int64_t) const { return Sparse{-1}; }
-    __device__ void sparse_step(Sparse&, const State&) const {}
+    __device__ void event() {}
 };
 
-struct ArStage {
-    static constexpr int NS = 2;
-    static constexpr int NBRK = 0;
-    static constexpr bool DENSE_OUT = true;
-    struct State { float z[2]; };  // yf, ys
-    struct Sparse { int rem; };
-    Geom g;
-    const float* xdb;  // [clips][U][C]
-    float* dif;        // [clips][U][C]
-    float fa, fr, sa, sr, floor_db;
-    int64_t L, W, n_chunks;
-    int64_t Wc;  // coarse (approximate-arithmetic) warm-up before the exact one
-    __device__ int64_t len() const { return g.U; }
-    __device__ int64_t brk(int) const { return 0; }
-    __device__ State init(int64_t, int) const { return State{{floor_db, floor_db}}; }
-    // Starting guess for the exact speculative warm-up at position u: the same
-    // followers run over the preceding Wc samples in plain fp32 fma arithmetic (a
-    // third of the instructions of the exact step).  Only a GUESS: exactness comes
-    // from the exact warm-up that follows plus the chunk-Jacobi verification.
-    struct Coarse {
-        static constexpr bool DENSE_OUT = false;
-        struct State { float z[2]; };
-        struct Sparse { int rem; };
-        Geom g;
-        float fa, fr, sa, sr;
-        __device__ float compute(State& s, float xv) const {
-            float d0 = xv - s.z[0], d1 = xv - s.z[1];
-            s.z[0] = fmaf(d0 > 0.0f ? fa : fr, d0, s.z[0]);
-            s.z[1] = fmaf(d1 > 0.0f ? sa : sr, d1, s.z[1]);
-            return 0.0f;
-        }
-        __device__ void sparse_step(Sparse&, const State&) const {}
-    };
-    __device__ State guess(int64_t clip, int c, int64_t u) const;
-    __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return xdb + (clip * g.U + u) * g.C + c; }
-    __device__ float* out_ptr(int64_t clip, int c, int64_t u) const { return dif + (clip * g.U + u) * g.C + c; }
-    __device__ float compute(State& s, float xv) const {
-        s.z[0] = ofp_ar_step(xv, s.z[0], fa, fr);
-        s.z[1] = ofp_ar_step(xv, s.z[1], sa, sr);
-        return s.z[0] - s.z[1];
+// ofp_ar_step for both followers (two independent chains: their operations interleave)
+struct ArStep {
+    float yf, ys, fa, fr, sa, sr;
+    __device__ float operator()(float xv) {
+        yf = ofp_ar_step(xv, yf, fa, fr);
+        ys = ofp_ar_step(xv, ys, sa, sr);
+        return yf - ys;
     }
-    __device__ Sparse sparse_begin(int64_t, int, int64_t) const { return Sparse{-1}; }
-    __device__ void sparse_step(Sparse&, const State&) const {}
+    __device__ void event() {}
 };
 
-struct MmStage {
-    static constexpr int NS = 2;
-    static constexpr int NBRK = 1;
-    static constexpr bool DENSE_OUT = false;
-    struct State { float z[2]; };  // mn, mx
-    struct Sparse {                 // writes the tracker state after each MAIN block
-        float* pmn;
-        float* pmx;
-        int rem;     // steps until the next block end (<0: warm-up region, no output)
-        int stride;  // C
-        int B;
-    };
-    Geom g;
-    const float* rel;  // [clips][U][C]
-    float* thr_mn;     // [clips][nb][C]
-    float* thr_mx;
-    float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
-    int64_t nb;
-    int64_t L, W, n_chunks;
-    __device__ int64_t len() const { return g.U; }
-    __device__ int64_t brk(int) const { return g.n_wb; }
-    __device__ State init(int64_t, int) const { return State{{min0, max0}}; }
-    // speculative start: the min from ABOVE (+inf: the first sample sets it; it coalesces with
-    // the true min at the first sample that resets the true one, which is frequent) and the max
-    // from BELOW (0: coalesces at the first sample that resets the true max)
-    __device__ State guess(int64_t, int, int64_t) const { return State{{__builtin_inff(), 0.f}}; }
-    __device__ const float* in_ptr(int64_t clip, int c, int64_t u) const { return rel + (clip * g.U + u) * g.C + c; }
-    __device__ float* out_ptr(int64_t, int, int64_t) const { return nullptr; }
-    // ofp_min_step / ofp_max_step, same operations, the two EMAs as one 2-wide vector
-    __device__ float compute(State& s, float xv) const {
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f IA = {ialpha_min, ialpha_max}, AL = {alpha_min, alpha_max};
-        const v2f m = {s.z[0], s.z[1]}, xx = {xv, xv};
-        const v2f e = m * IA + xx * AL;
-        float mn = xv < s.z[0] ? xv : e.x;
-        mn = xv < minmin ? minmin : mn;
-        const float mx = xv > s.z[1] ? xv : e.y;
-        s.z[0] = mn;
-        s.z[1] = mx;
+// the same followers in plain fp32 fma arithmetic: only a GUESS generator for the exact warm-up
+struct ArCoarse {
+    float yf, ys, fa, fr, sa, sr;
+    __device__ float operator()(float xv) {
+        const float d0 = xv - yf, d1 = xv - ys;
+        yf = fmaf(d0 > 0.0f ? fa : fr, d0, yf);
+        ys = fmaf(d1 > 0.0f ? sa : sr, d1, ys);
         return 0.0f;
     }
-    // max tracker only: the long part of the speculative warm-up exists for the max (it
-    // coalesces only at samples that reset it); the min snaps to `minmin` at every sample
-    // below it and needs only the short full-step tail of the warm-up.
-    struct MaxOnly {
-        static constexpr bool DENSE_OUT = false;
-        struct State { float z[1]; };
-        struct Sparse { int rem; };
-        Geom g;
-        float alpha_max, ialpha_max;
-        __device__ float compute(State& s, float xv) const {
-            s.z[0] = ofp_max_step(xv, s.z[0], ialpha_max, alpha_max);
-            return 0.0f;
-        }
-        __device__ void sparse_step(Sparse&, const State&) const {}
-    };
-    static constexpr int64_t WARM_FULL = 4096;
-    __device__ Sparse sparse_begin(int64_t clip, int c, int64_t u) const {
-        Sparse sp;
-        sp.stride = g.C;
-        sp.B = g.B;
-        int64_t m = u - g.n_wb;
-        if (m < 0) {
-            sp.rem = -1;
-            sp.pmn = sp.pmx = nullptr;
-        } else {
-            int64_t j = m / g.B;
-            sp.rem = (int)(g.B - 1 - (m - j * g.B));
-            sp.pmn = thr_mn + (clip * nb + j) * g.C + c;
-            sp.pmx = thr_mx + (clip * nb + j) * g.C + c;
-        }
-        return sp;
+    __device__ void event() {}
+};
+
+// ofp_min_step / ofp_max_step, the two EMAs as one 2-wide vector; event() stores the
+// tracker state after a MAIN block (thresholds are taken from the post-block state, :762-763)
+struct MmStep {
+    float mn, mx, minmin;
+    v2f IA, AL;
+    float* pmn;
+    float* pmx;
+    int stride, B;
+    int* rem;
+    __device__ float operator()(float xv) {
+        const v2f m = {mn, mx}, xx = {xv, xv};
+        const v2f e = m * IA + xx * AL;
+        float a = xv < mn ? xv : e.x;
+        a = xv < minmin ? minmin : a;
+        const float b = xv > mx ? xv : e.y;
+        mn = a;
+        mx = b;
+        return 0.0f;
     }
-    __device__ void sparse_step(Sparse& sp, const State& s) const {
-        if (sp.rem == 0) {
-            *sp.pmn = s.z[0];
-            *sp.pmx = s.z[1];
-            sp.pmn += sp.stride;
-            sp.pmx += sp.stride;
-            sp.rem = sp.B;
-        }
-        sp.rem -= 1;
+    __device__ void event() {
+        *pmn = mn;
+        *pmx = mx;
+        pmn += stride;
+        pmx += stride;
+        *rem = B;  // walk() decrements right after: B-1 further steps to the next block end
     }
 };
 
-// run positions [t0, t1) of an affine span: inputs are prefetched PB steps ahead
-// into registers (their addresses do not depend on the state), pointers advance
-// by C floats per step.  HAS_OUT / SPARSE are decided once per span so the step
-// sequence itself is straight-line code.
-template <class S, bool HAS_OUT, bool SPARSE, int PB>
-__device__ __forceinline__ void process_batch(const S& st, typename S::State& s, const float (&v)[PB], float*& op,
-                                              typename S::Sparse& sp, int64_t stride) {
-    if (SPARSE && sp.rem < PB) {  // a block ends inside this batch (once every B/PB batches)
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            st.compute(s, v[i]);
-            st.sparse_step(sp, s);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            float o = st.compute(s, v[i]);
-            if (HAS_OUT) op[i * stride] = o;
-        }
-        if (HAS_OUT) op += PB * stride;
-        if (SPARSE) sp.rem -= PB;
+struct MaxStep {  // the max alone: the long part of the tracker's speculative warm-up
+    float mx, ia, al;
+    __device__ float operator()(float xv) {
+        mx = ofp_max_step(xv, mx, ia, al);
+        return 0.0f;
     }
-}
-
-template <class S, bool HAS_OUT, bool SPARSE, int PB = 16>
-__device__ __forceinline__ void run_affine_impl(const S& st, typename S::State& s, const float* ip, float* op,
-                                                typename S::Sparse sp, int64_t n) {
-    const int64_t stride = st.g.C;
-    float A[PB], Bv[PB];
-    if (n >= PB) {
-#pragma unroll
-        for (int i = 0; i < PB; ++i) A[i] = ip[i * stride];
-        ip += PB * stride;
-        n -= PB;
-        // two batches per iteration, ping-pong between the register sets (no copies)
-        while (n >= 2 * PB) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) Bv[i] = ip[i * stride];
-            ip += PB * stride;
-            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) A[i] = ip[i * stride];
-            ip += PB * stride;
-            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, Bv, op, sp, stride);
-            n -= 2 * PB;
-        }
-        if (n >= PB) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) Bv[i] = ip[i * stride];
-            ip += PB * stride;
-            n -= PB;
-            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
-            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, Bv, op, sp, stride);
-        } else {
-            process_batch<S, HAS_OUT, SPARSE, PB>(st, s, A, op, sp, stride);
-        }
-    }
-    for (; n > 0; --n) {
-        float o = st.compute(s, *ip);
-        ip += stride;
-        if (HAS_OUT) { *op = o; op += stride; }
-        if (SPARSE) st.sparse_step(sp, s);
-    }
-}
-
-__device__ __forceinline__ ArStage::State ArStage::guess(int64_t clip, int c, int64_t u) const {
-    int64_t t0 = u - Wc;
-    Coarse cs{g, fa, fr, sa, sr};
-    Coarse::State s;
-    if (t0 <= 0) {
-        t0 = 0;
-        s.z[0] = s.z[1] = floor_db;  // the true initial state
-    } else {
-        s.z[0] = s.z[1] = *in_ptr(clip, c, t0);
-    }
-    if (u > t0) run_affine_impl<Coarse, false, false, 64>(cs, s, in_ptr(clip, c, t0), nullptr, Coarse::Sparse{-1}, u - t0);
-    return State{{s.z[0], s.z[1]}};
-}
-
-template <class S, bool OUT>
-__device__ __forceinline__ void run_affine(const S& st, typename S::State& s, int64_t clip, int c,
-                                           int64_t t0, int64_t t1) {
-    const float* ip = st.in_ptr(clip, c, t0);
-    float* op = (OUT && S::DENSE_OUT) ? st.out_ptr(clip, c, t0) : nullptr;
-    typename S::Sparse sp = st.sparse_begin(clip, c, t0);
-    const bool sparse = OUT && !S::DENSE_OUT && sp.rem >= 0;
-    const int64_t n = t1 - t0;
-    if (S::DENSE_OUT) {
-        if (op) run_affine_impl<S, true, false>(st, s, ip, op, sp, n);
-        else run_affine_impl<S, false, false>(st, s, ip, op, sp, n);
-    } else {
-        if (sparse) run_affine_impl<S, false, true>(st, s, ip, op, sp, n);
-        else run_affine_impl<S, false, false>(st, s, ip, op, sp, n);
-    }
-}
-
-template <class S, bool OUT>
-__device__ __forceinline__ void run_span(const S& st, typename S::State& s, int64_t clip, int c,
-                                         int64_t t0, int64_t t1) {
-    int64_t a = t0;
-#pragma unroll
-    for (int i = 0; i <= S::NBRK; ++i) {
-        int64_t b = t1;
-        if (i < S::NBRK) b = min(max(st.brk(i), a), t1);
-        if (b > a) run_affine<S, OUT>(st, s, clip, c, a, b);
-        a = b;
-    }
-}
-
-// speculative warm-up over [ws, start): the exact step by default
-template <class S>
-__device__ __forceinline__ void warm_up(const S& st, typename S::State& s, int64_t clip, int c, int64_t ws,
-                                        int64_t start) {
-    run_span<S, false>(st, s, clip, c, ws, start);
-}
-template <>
-__device__ __forceinline__ void warm_up<MmStage>(const MmStage& st, MmStage::State& s, int64_t clip, int c,
-                                                 int64_t ws, int64_t start) {
-    const int64_t mid = max(ws, start - MmStage::WARM_FULL);
-    if (mid > ws && ws > 0) {  // (ws == 0 starts from the true state: run the full step throughout)
-        MmStage::MaxOnly mo{st.g, st.alpha_max, st.ialpha_max};
-        MmStage::MaxOnly::State ms{{s.z[1]}};
-        run_affine_impl<MmStage::MaxOnly, false, false, 64>(mo, ms, st.in_ptr(clip, c, ws), nullptr,
-                                                            MmStage::MaxOnly::Sparse{-1}, mid - ws);
-        s.z[1] = ms.z[0];
-        ws = mid;
-    }
-    run_span<MmStage, false>(st, s, clip, c, ws, start);
-}
-
-// One chunk-Jacobi pass.  Thread = (clip, chunk, channel), channel fastest.
-// State words are compared and stored as raw bits (NaN-safe).
-template <class S>
-__global__ __launch_bounds__(64) void k_jacobi(S st, int pass, int64_t n_threads,
-                                               const uint32_t* __restrict__ end_prev,
-                                               uint32_t* __restrict__ end_next,
-                                               uint32_t* __restrict__ used, int* changed) {
-    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;
-    const int C = st.g.C;
-    const int c = (int)(id % C);
-    const int64_t r = id / C;
-    const int64_t k = r % st.n_chunks;
-    const int64_t clip = r / st.n_chunks;
-    const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.len());
-    const int64_t sidx = ((clip * st.n_chunks + k) * C + c) * S::NS;
-    typename S::State s;
-    if (pass == 0) {
-        int64_t ws = start - st.W;
-        if (ws <= 0) {
-            ws = 0;
-            s = st.init(clip, c);
-        } else {
-            s = st.guess(clip, c, ws);
-        }
-        warm_up(st, s, clip, c, ws, start);
-#pragma unroll
-        for (int i = 0; i < S::NS; ++i) used[sidx + i] = ofp_f2u(s.z[i]);
-        run_span<S, true>(st, s, clip, c, start, end);
-#pragma unroll
-        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = ofp_f2u(s.z[i]);
-        return;
-    }
-    if (k == 0) {
-#pragma unroll
-        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = end_prev[sidx + i];
-        return;
-    }
-    const int64_t pidx = sidx - (int64_t)C * S::NS;  // chunk k-1, same clip and channel
-    bool same = true;
-    uint32_t in[S::NS];
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-        in[i] = end_prev[pidx + i];
-        same &= (in[i] == used[sidx + i]);
-    }
-    if (same) {
-#pragma unroll
-        for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = end_prev[sidx + i];
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-        s.z[i] = ofp_u2f(in[i]);
-        used[sidx + i] = in[i];
-    }
-    run_span<S, true>(st, s, clip, c, start, end);
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) end_next[sidx + i] = ofp_f2u(s.z[i]);
-    atomicAdd(changed, 1);
-}
-
-// ---- 4-lane form of the IIR stage ---------------------------------------------------
-// The IIR is the stage whose speculation rarely verifies (section 3 of DESIGN.md), so
-// its cost is (samples walked sequentially) x (time per step), and a lone wave issues one
-// instruction per 4 cycles.  Here FOUR lanes cooperate on one chain: lane k of a quad
-// owns delay z_k and the taps (b_{k+1}, a_{k+1}); z_0 and z_{k+1} arrive through DPP
-// quad permutes, so a step is ~9 instructions instead of ~22.  Lane k also loads
-// sample 4m+k and stores output 4m+k, i.e. one load and one store per four steps.
-// The operations and their order are those of ofp_df2t4_step (the last tap adds
-// -0.0f, exact for every addend), so results are bit-identical.
-template <int CTRL>
-__device__ __forceinline__ float qperm(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
-struct Hp4 {
-    float z, Bk, Ak, b0;
-    bool last;  // lane 3 of the quad
+    __device__ void event() {}
 };
 
-__device__ __forceinline__ float hp4_step(float x, Hp4& h) {
-    const float bx = h.Bk * x;
-    const float y = qperm<0x00>(h.z) + h.b0 * x;  // z0 of the quad
-    float zn = qperm<0xF9>(h.z);                   // z_{k+1}
-    zn = h.last ? -0.0f : zn;
-    const float t = zn + bx;
-    h.z = t - h.Ak * y;
-    return y;
-}
-
-template <bool HAS_OUT>
-__device__ __forceinline__ void hp4_quad_block(float xr, Hp4& h, int k4, float* opl) {
-    const float y0 = hp4_step(qperm<0x00>(xr), h);
-    const float y1 = hp4_step(qperm<0x55>(xr), h);
-    const float y2 = hp4_step(qperm<0xAA>(xr), h);
-    const float y3 = hp4_step(qperm<0xFF>(xr), h);
-    if (HAS_OUT) {
-        float yk = k4 == 0 ? y0 : y1;
-        yk = k4 == 2 ? y2 : yk;
-        yk = k4 == 3 ? y3 : yk;
-        *opl = yk;
+// ---------------------------------------------------------------------------
+// k_transpose_in: caller audio [clip][N][C] -> planar [clip][C][N]
+__global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
+                                                      int64_t N, int C, int TU) {
+    extern __shared__ float tile[];  // [C][TU+1]
+    const int64_t clip = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * TU;
+    const int nt = (int)min<int64_t>(TU, N - t0);
+    const float* src = x + (clip * N + t0) * C;
+    const int total = nt * C;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int t = i / C, c = i - t * C;
+        tile[c * (TU + 1) + t] = src[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i / nt, t = i - c * nt;
+        xt[(clip * C + c) * N + t0 + t] = tile[c * (TU + 1) + t];
     }
 }
 
-// positions [t0, t1) of an affine span (addresses affine in the position)
-template <bool HAS_OUT>
-__device__ __forceinline__ void hp4_affine(Hp4& h, int k4, const float* ip, float* op, int64_t stride, int64_t n) {
-    constexpr int PB = 8;  // registers of prefetch = 4*PB steps
-    const float* ipl = ip + k4 * stride;
-    float* opl = HAS_OUT ? op + k4 * stride : nullptr;
-    const int64_t s4 = 4 * stride;
-    int64_t nb = n >> 2;  // blocks of four steps
-    float A[PB], Bv[PB];
-    if (nb >= PB) {
-#pragma unroll
-        for (int i = 0; i < PB; ++i) A[i] = ipl[i * s4];
-        ipl += PB * s4;
-        nb -= PB;
-        while (nb >= 2 * PB) {
-#pragma unroll
-            for (int i = 0; i < PB; ++i) Bv[i] = ipl[i * s4];
-            ipl += PB * s4;
-#pragma unroll
-            for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(A[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
-            if (HAS_OUT) opl += PB * s4;
-#pragma unroll
-            for (int i = 0; i < PB; ++i) A[i] = ipl[i * s4];
-            ipl += PB * s4;
-#pragma unroll
-            for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(Bv[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
-            if (HAS_OUT) opl += PB * s4;
-            nb -= 2 * PB;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) hp4_quad_block<HAS_OUT>(A[i], h, k4, HAS_OUT ? opl + i * s4 : nullptr);
-        if (HAS_OUT) opl += PB * s4;
-    }
-    for (; nb > 0; --nb) {
-        hp4_quad_block<HAS_OUT>(*ipl, h, k4, opl);
-        ipl += s4;
-        if (HAS_OUT) opl += s4;
-    }
-    // fewer than four steps left: every lane reads the same sample, lane 0 stores
-    const float* ipr = ipl - k4 * stride;
-    float* opr = HAS_OUT ? opl - k4 * stride : nullptr;
-    for (int r = (int)(n & 3); r > 0; --r) {
-        const float y = hp4_step(*ipr, h);
-        ipr += stride;
-        if (HAS_OUT) {
-            if (k4 == 0) *opr = y;
-            opr += stride;
-        }
-    }
-}
+// ---------------------------------------------------------------------------
+// follower stage (chunk-Jacobi).  thread = (clip, chunk, channel)
+struct ArArgs {
+    Geom g;
+    const float* xdb;  // planar [clip*C + c][U]
+    float* dif;        // planar
+    float fa, fr, sa, sr, floor_db;
+    int64_t L, W, Wc, n_chunks;
+};
 
-template <bool OUT>
-__device__ __forceinline__ void hp4_span(const HpStage& st, Hp4& h, int k4, int64_t clip, int c, int64_t t0,
-                                         int64_t t1) {
-    int64_t a = t0;
-#pragma unroll
-    for (int i = 0; i <= HpStage::NBRK; ++i) {
-        int64_t b = t1;
-        if (i < HpStage::NBRK) b = min(max(st.brk(i), a), t1);
-        if (b > a) {
-            const float* ip = st.in_ptr(clip, c, a);
-            float* op = OUT ? st.out_ptr(clip, c, a) : nullptr;
-            if (op) hp4_affine<true>(h, k4, ip, op, st.g.C, b - a);
-            else hp4_affine<false>(h, k4, ip, nullptr, st.g.C, b - a);
-        }
-        a = b;
-    }
-}
-
-// chunk-Jacobi pass, thread = (clip, chunk, channel, delay k4); same protocol as k_jacobi
-__global__ __launch_bounds__(64) void k_jacobi_hp4(HpStage st, int pass, int64_t n_threads,
-                                                   const uint32_t* __restrict__ end_prev,
-                                                   uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
-                                                   int* changed) {
+// The stage is split into LEAN kernels, one walk instantiation each: measured on gfx950, the
+// very same loop runs 3-4x slower inside a kernel that also carries the other (heavily
+// unrolled) walk instantiations than alone (11 ns/step vs 35-50 for the max tracker), so
+// code size per kernel is kept small.
+//   k_ar_coarse: guess at the start of the exact warm-up, from the followers run in fp32-fma
+//                arithmetic over the preceding Wc samples (a third of the instructions)
+//   k_ar_warm  : exact speculative warm-up -> used[k], the state chunk k starts from
+//   k_ar_chunk : pass 0 runs every chunk from used[k]; pass j >= 1 re-runs the chunks whose
+//                used[k] differs bitwise from end[k-1], from end[k-1]
+__global__ __launch_bounds__(64) void k_ar_coarse(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;  // n_threads is a multiple of 4: quads are never split
-    const int k4 = (int)(id & 3);
-    const int64_t q = id >> 2;
-    const int C = st.g.C;
-    const int c = (int)(q % C);
-    const int64_t r = q / C;
-    const int64_t k = r % st.n_chunks;
-    const int64_t clip = r / st.n_chunks;
-    const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.len());
-    const int64_t sidx = ((clip * st.n_chunks + k) * C + c) * 4 + k4;
-    Hp4 h;
-    h.Bk = st.b[k4 + 1];
-    h.Ak = st.a[k4 + 1];
-    h.b0 = st.b[0];
-    h.last = k4 == 3;
-    if (pass == 0) {
-        int64_t ws = max<int64_t>(start - st.W, 0);
-        h.z = 0.0f;  // true initial state at 0, guess elsewhere
-        hp4_span<false>(st, h, k4, clip, c, ws, start);
-        used[sidx] = ofp_f2u(h.z);
-        hp4_span<true>(st, h, k4, clip, c, start, end);
-        end_next[sidx] = ofp_f2u(h.z);
-        return;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;       // chunk fastest: neighbouring lanes do equal work
+    const int64_t chain = id / a.n_chunks;   // clip*C + c
+    const int64_t ws = max<int64_t>(k * a.L - a.W, 0);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const float* xs = a.xdb + chain * a.g.U;
+    ArCoarse cs{a.floor_db, a.floor_db, a.fa, a.fr, a.sa, a.sr};  // true initial state (:697-702)
+    if (ws > 0) {
+        const int64_t t0 = max<int64_t>(ws - a.Wc, 0);
+        if (t0 > 0) cs.yf = cs.ys = xs[t0];
+        int norem = -1;
+        walk<16, 0, false>(xs + t0, nullptr, ws - t0, norem, cs);
     }
-    if (k == 0) {
-        end_next[sidx] = end_prev[sidx];
-        return;
-    }
-    const uint32_t in = end_prev[sidx - (int64_t)C * 4];
-    const bool diff = in != used[sidx];
-    // the four lanes of a quad decide together (any delay differs -> re-run the chain)
-    unsigned long long m = __ballot(diff);
-    const int lane = threadIdx.x & 63;
-    const bool rerun = ((m >> (lane & ~3)) & 0xfull) != 0ull;
-    if (!rerun) {
-        end_next[sidx] = end_prev[sidx];
-        return;
-    }
-    h.z = ofp_u2f(in);
-    used[sidx] = in;
-    hp4_span<true>(st, h, k4, clip, c, start, end);
-    end_next[sidx] = ofp_f2u(h.z);
-    if (k4 == 0) atomicAdd(changed, 1);
+    used[sidx] = ofp_f2u(cs.yf);
+    used[sidx + 1] = ofp_f2u(cs.ys);
 }
 
-// ---- IIR stage, multi-candidate speculation ------------------------------------------
-// A single speculative warm-up coalesces with the true trajectory only at loud events
-// and only with probability ~1/2 per event, so chunk-Jacobi on the IIR walks long
-// stretches sequentially.  Instead every chunk start gets R candidate states, from R
-// speculative runs that begin at different offsets (different rounding histories = R
-// independent chances to coalesce), each continued to the chunk end:
-//     U[k][r] = candidate state at the start of chunk k,  E[k][r] = state at its end.
-// Resolution then walks each chain: the true start of chunk k is E[k-1][sel[k-1]];
-// if some U[k][r] equals it bitwise, sel[k] = r and the walk continues for free,
-// otherwise chunk k is run once from the true state (slot R) and the walk resumes.
-// Finally every chunk is run from its verified start state and writes the output.
-// Only bitwise-verified states are ever used, so the result is the sequential one.
+__global__ __launch_bounds__(64) void k_ar_warm(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t ws = max<int64_t>(start - a.W, 0);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const float* xs = a.xdb + chain * a.g.U;
+    ArStep s{ofp_u2f(used[sidx]), ofp_u2f(used[sidx + 1]), a.fa, a.fr, a.sa, a.sr};
+    int norem = -1;
+    walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
+    used[sidx] = ofp_f2u(s.yf);
+    used[sidx + 1] = ofp_f2u(s.ys);
+}
+
+__global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_threads,
+                                                 const uint32_t* __restrict__ end_prev,
+                                                 uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                 int* changed) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t end = min(start + a.L, a.g.U);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    uint32_t i0 = used[sidx], i1 = used[sidx + 1];
+    if (pass > 0) {
+        if (k == 0) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
+        if (p0 == i0 && p1 == i1) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        i0 = p0;
+        i1 = p1;
+        used[sidx] = i0;
+        used[sidx + 1] = i1;
+        atomicAdd(changed, 1);
+    }
+    ArStep s{ofp_u2f(i0), ofp_u2f(i1), a.fa, a.fr, a.sa, a.sr};
+    int norem = -1;
+    walk<8, 4, false>(a.xdb + chain * a.g.U + start, a.dif + chain * a.g.U + start, end - start, norem, s);
+    end_next[sidx] = ofp_f2u(s.yf);
+    end_next[sidx + 1] = ofp_f2u(s.ys);
+}
+
+// ---------------------------------------------------------------------------
+// tracker stage (chunk-Jacobi)
+struct MmArgs {
+    Geom g;
+    const float* rel;  // planar [clip*C + c][U]
+    float* thr_mn;     // [clips][nb][C] tracker state after each MAIN block
+    float* thr_mx;
+    float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
+    int64_t nb, L, W, n_chunks;
+};
+
+// lean kernels, as for the followers:
+//   k_mm_max  : the long part of the speculative warm-up runs the max alone.  The max is
+//               guessed from BELOW (0): it coalesces with the true max at the first sample
+//               that resets the true one, which needs the long window.
+//   k_mm_warm : the last WARM_FULL samples before the chunk run the full step; the min is
+//               guessed from ABOVE (+inf): it coalesces at the first sample that resets the
+//               true min, which is frequent.
+//   k_mm_chunk: chunk with threshold output at the block ends of the MAIN part; pass 0 from
+//               used[k], pass j >= 1 re-runs chunks whose used[k] != end[k-1] bitwise.
+constexpr int64_t MM_WARM_FULL = 4096;
+
+__global__ __launch_bounds__(64) void k_mm_max(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t ws = max<int64_t>(start - a.W, 0);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const float* rs = a.rel + chain * a.g.U;
+    // The max recurrence does not involve the min, so running it alone is EXACT for the max:
+    // chunks whose window reaches back to the stream start carry the true max (from max0);
+    // the others start from the guess 0.  Either way the min is handed over as +inf unless the
+    // full-step part starts at the stream start itself.
+    const int64_t mid = max(ws, start - MM_WARM_FULL);
+    MaxStep mo{ws > 0 ? 0.0f : a.max0, a.ialpha_max, a.alpha_max};
+    int norem = -1;
+    walk<16, 0, false>(rs + ws, nullptr, mid - ws, norem, mo);
+    const float mx = mo.mx;
+    const float mn = mid > 0 ? __builtin_inff() : a.min0;
+    used[sidx] = ofp_f2u(mn);
+    used[sidx + 1] = ofp_f2u(mx);
+}
+
+__global__ __launch_bounds__(64) void k_mm_warm(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t ws = max(max<int64_t>(start - a.W, 0), start - MM_WARM_FULL);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    MmStep s;
+    s.mn = ofp_u2f(used[sidx]);
+    s.mx = ofp_u2f(used[sidx + 1]);
+    s.minmin = a.minmin;
+    s.IA = v2f{a.ialpha_min, a.ialpha_max};
+    s.AL = v2f{a.alpha_min, a.alpha_max};
+    s.pmn = s.pmx = nullptr;
+    int norem = -1;
+    s.rem = &norem;
+    walk<8, 0, false>(a.rel + chain * a.g.U + ws, nullptr, start - ws, norem, s);
+    used[sidx] = ofp_f2u(s.mn);
+    used[sidx + 1] = ofp_f2u(s.mx);
+}
+
+__global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_threads,
+                                                 const uint32_t* __restrict__ end_prev,
+                                                 uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                 int* changed) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t end = min(start + a.L, a.g.U);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    uint32_t i0 = used[sidx], i1 = used[sidx + 1];
+    if (pass > 0) {
+        if (k == 0) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
+        if (p0 == i0 && p1 == i1) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        i0 = p0;
+        i1 = p1;
+        used[sidx] = i0;
+        used[sidx + 1] = i1;
+        atomicAdd(changed, 1);
+    }
+    const int C = a.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
+    MmStep s;
+    s.mn = ofp_u2f(i0);
+    s.mx = ofp_u2f(i1);
+    s.minmin = a.minmin;
+    s.IA = v2f{a.ialpha_min, a.ialpha_max};
+    s.AL = v2f{a.alpha_min, a.alpha_max};
+    s.stride = C;
+    s.B = a.g.B;
+    // steps to the first block end of the MAIN part at or after `start` (events are disabled
+    // while rem < 0, i.e. never here: the count simply runs through the warm part)
+    int rem;
+    const int64_t m = start - a.g.n_wb;  // position in the main part (negative: still warm part)
+    int64_t j = 0;
+    if (m >= 0) {
+        j = m / a.g.B;
+        rem = (int)(a.g.B - 1 - (m - j * a.g.B));
+    } else {
+        rem = (int)min<int64_t>(-m + a.g.B - 1, 0x7fffffff);
+    }
+    s.pmn = a.thr_mn + (clip * a.nb + j) * C + c;
+    s.pmx = a.thr_mx + (clip * a.nb + j) * C + c;
+    s.rem = &rem;
+    walk<8, 0, true>(a.rel + chain * a.g.U + start, nullptr, end - start, rem, s);
+    end_next[sidx] = ofp_f2u(s.mn);
+    end_next[sidx + 1] = ofp_f2u(s.mx);
+}
+
+// ---------------------------------------------------------------------------
+// IIR stage
+struct HpArgs {
+    Geom g;
+    const float* xt;  // planar audio [clip*C + c][N]
+    float* out;       // planar [clip*C + c][U]
+    float b[5], a[5];
+    int64_t L, W, n_chunks;
+};
+
+// positions [t0, t1) of the hp stream; the stream<->memory mapping is affine between the
+// breaks n_wb and n_w (detection.py:828-834: the tail of the warm-up passes the filter only)
+template <bool OUT, class F>
+__device__ __forceinline__ void hp_span(const HpArgs& a, F& f, int64_t chain, int64_t t0, int64_t t1) {
+    const float* xs = a.xt + chain * a.g.N;
+    float* os = a.out + chain * a.g.U;
+    int64_t p = t0;
+    int norem = -1;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        const int64_t br = i == 0 ? a.g.n_wb : (i == 1 ? a.g.n_w : t1);
+        const int64_t e = min(max(br, p), t1);
+        if (e > p) {
+            const int64_t u = hp_dst(a.g, p);
+            if (OUT && u >= 0) walk<8, 1, false>(xs + hp_src(a.g, p), os + u, e - p, norem, f);
+            else walk<8, 0, false>(xs + hp_src(a.g, p), nullptr, e - p, norem, f);
+        }
+        p = e;
+    }
+}
+
 constexpr int HP_MAXR = 16;
 
 struct HpCand {
-    HpStage st;
+    HpArgs st;
     int R;            // candidates per chunk (slots 0..R-1; slot R = exact re-run)
     int64_t delta;    // offset between candidate starts
     uint32_t* U;      // [clips][chunks][C][R+1][4]
@@ -629,70 +537,36 @@ struct HpCand {
     }
 };
 
-// pass A: thread = (clip, chunk, channel, candidate, delay)
+
+// pass A: thread = (clip, channel, candidate, chunk), chunk fastest
 __global__ __launch_bounds__(64) void k_hp_candidates(HpCand a, int64_t n_threads) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
-    const HpStage& st = a.st;
-    const int k4 = (int)(id & 3);
-    int64_t q = id >> 2;
-    const int r = (int)(q % a.R);
-    q /= a.R;
-    const int C = st.g.C;
-    const int c = (int)(q % C);
-    q /= C;
-    const int64_t k = q % st.n_chunks;
-    const int64_t clip = q / st.n_chunks;
-    const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.len());
-    const int64_t si = a.slot(clip, k, c, r) + k4;
-    if (k4 == 0 && r == 0) {
-        a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
-        a.done[(clip * st.n_chunks + k) * C + c] = 0;
-        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
-    }
-    Hp4 h;
-    h.Bk = st.b[k4 + 1];
-    h.Ak = st.a[k4 + 1];
-    h.b0 = st.b[0];
-    h.last = k4 == 3;
-    h.z = 0.0f;
-    const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
-    hp4_span<false>(st, h, k4, clip, c, ws, start);
-    a.U[si] = ofp_f2u(h.z);
-    hp4_span<false>(st, h, k4, clip, c, start, end);
-    a.E[si] = ofp_f2u(h.z);
-}
-
-// pass A, one lane per candidate (packed-fp32 step of HpStage::compute): four times
-// fewer lanes than the quad form, which matters here because EVERY candidate of every
-// chunk runs (thousands of waves); the quad form is kept for the sparse re-runs.
-__global__ __launch_bounds__(64) void k_hp_candidates1(HpCand a, int64_t n_threads) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;
-    const HpStage& st = a.st;
+    const HpArgs& st = a.st;
     int64_t q = id;
-    const int C = st.g.C;
-    const int c = (int)(q % C);
-    q /= C;
-    const int r = (int)(q % a.R);   // candidates of one chunk sit in different waves' lanes: same trip count per lane group
-    q /= a.R;
     const int64_t k = q % st.n_chunks;
-    const int64_t clip = q / st.n_chunks;
+    q /= st.n_chunks;
+    const int r = (int)(q % a.R);
+    const int64_t chain = q / a.R;  // clip*C + c
+    const int C = st.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
     const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.len());
+    const int64_t end = min(start + st.L, st.g.V);
     const int64_t si = a.slot(clip, k, c, r);
     if (r == 0) {
         a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
         a.done[(clip * st.n_chunks + k) * C + c] = 0;
-        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty
+        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
     }
-    HpStage::State s = st.init(clip, c);
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    s.z[0] = s.z[1] = s.z[2] = s.z[3] = 0.0f;  // true state at 0 (detection.py:497), guess elsewhere
     const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
-    run_span<HpStage, false>(st, s, clip, c, ws, start);
+    hp_span<false>(st, s, chain, ws, start);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.U[si + i] = ofp_f2u(s.z[i]);
-    run_span<HpStage, false>(st, s, clip, c, start, end);
+    hp_span<false>(st, s, chain, start, end);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.E[si + i] = ofp_f2u(s.z[i]);
 }
@@ -772,14 +646,12 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
 __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
-    const HpStage& st = a.st;
-    const int k4 = (int)(id & 3);
-    int64_t q = id >> 2;
+    const HpArgs& st = a.st;
+    const int64_t k = id % st.n_chunks;
+    const int64_t chain = id / st.n_chunks;
     const int C = st.g.C;
-    const int c = (int)(q % C);
-    q /= C;
-    const int64_t k = q % st.n_chunks;
-    const int64_t clip = q / st.n_chunks;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
     const int64_t ci = (clip * st.n_chunks + k) * C + c;
     if (a.done[ci]) return;
     int sp = 0;
@@ -787,43 +659,46 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
         sp = a.sel[ci - C];
         if (sp < 0) return;  // predecessor not resolved yet
     }
-    Hp4 h;
-    h.Bk = st.b[k4 + 1];
-    h.Ak = st.a[k4 + 1];
-    h.b0 = st.b[0];
-    h.last = k4 == 3;
-    const uint32_t xin = (k == 0) ? 0u : a.E[a.slot(clip, k - 1, c, sp) + k4];
-    h.z = ofp_u2f(xin);
-    const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.len());
-    hp4_span<true>(st, h, k4, clip, c, start, end);
-    const bool unresolved = a.sel[ci] < 0;
-    if (unresolved) {
-        a.U[a.slot(clip, k, c, a.R) + k4] = xin;
-        a.E[a.slot(clip, k, c, a.R) + k4] = ofp_f2u(h.z);
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    uint32_t xin[4] = {0u, 0u, 0u, 0u};
+    if (k > 0) {
+        const uint32_t* e = a.E + a.slot(clip, k - 1, c, sp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xin[i] = e[i];
     }
-    // sel[ci] is NOT written here: a successor chunk running in this same launch must not
-    // see a slot that is still being filled.  The next k_hp_match finds slot R (its U equals
-    // the predecessor's end state by construction) and k_hp_resolve then selects it.
-    if (k4 == 0) a.done[ci] = 1;  // the four lanes read done[] above, before this write (one wave, in order)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.z[i] = ofp_u2f(xin[i]);
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.g.V);
+    hp_span<true>(st, s, chain, start, end);
+    if (a.sel[ci] < 0) {
+        // no candidate matched: this exact run becomes slot R.  sel[ci] itself is NOT written
+        // here (a successor running in this same launch must not see a half-filled slot); the
+        // next k_hp_match finds slot R and k_hp_resolve selects it.
+        uint32_t* u = a.U + a.slot(clip, k, c, a.R);
+        uint32_t* e = a.E + a.slot(clip, k, c, a.R);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i] = xin[i];
+            e[i] = ofp_f2u(s.z[i]);
+        }
+    }
+    a.done[ci] = 1;
 }
 
-// ---- elementwise stages ----------------------------------------------------
-// rectified dB (detection.py:747-748).  from_x: no high-pass, read the audio
-// through the stream mapping; else in place on the filtered buffer.
-__global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict__ x,
-                                                 float* __restrict__ buf, int64_t n_clips,
-                                                 int from_x, float floor_db) {
-    const int64_t per_clip = g.U * g.C;
-    const int64_t total = n_clips * per_clip;
+// ---- elementwise stages (planar, in place) -------------------------------------------
+// rectified dB (detection.py:747-748).  from_x: no high-pass, read the audio through the
+// stream mapping; else in place on the filtered buffer.
+__global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict__ xt, float* __restrict__ buf,
+                                                 int64_t n_chains, int from_x, float floor_db) {
+    const int64_t total = n_chains * g.U;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         float v;
         if (from_x) {
-            int64_t clip = i / per_clip, rem = i % per_clip;
-            int64_t u = rem / g.C;
-            int c = (int)(rem % g.C);
-            v = x[(clip * g.N + u_src(g, u)) * g.C + c];
+            const int64_t chain = i / g.U, u = i - chain * g.U;
+            v = xt[chain * g.N + u_src(g, u)];
         } else {
             v = buf[i];
         }
@@ -831,22 +706,30 @@ __global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict
     }
 }
 
-// back to linear (detection.py:753-754), in place; main part also to the caller's rel
-__global__ __launch_bounds__(256) void k_rel_linear(Geom g, float* __restrict__ buf,
-                                                    float* __restrict__ rel_out, int64_t n_clips,
-                                                    float floor_db) {
-    const int64_t per_clip = g.U * g.C;
-    const int64_t total = n_clips * per_clip;
-    const int64_t warm = g.n_wb * g.C;
-    const int64_t main = g.Nm * g.C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float v = ofp_rel_linear(buf[i], floor_db);
-        buf[i] = v;
-        if (rel_out) {
-            int64_t clip = i / per_clip, rem = i % per_clip;
-            if (rem >= warm) rel_out[clip * main + (rem - warm)] = v;
-        }
+// back to linear (detection.py:753-754), planar in place; the MAIN part is also written to
+// the caller's interleaved [N'][C] array through an LDS tile transpose.
+__global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
+                                                 float floor_db, int TU) {
+    extern __shared__ float tile[];  // [C][TU+1]
+    const int C = g.C;
+    const int64_t clip = blockIdx.y;
+    const int64_t u0 = (int64_t)blockIdx.x * TU;
+    const int nt = (int)min<int64_t>(TU, g.U - u0);
+    const int total = nt * C;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i / nt, t = i - c * nt;
+        float* p = buf + (clip * C + c) * g.U + u0 + t;
+        const float v = ofp_rel_linear(*p, floor_db);
+        *p = v;
+        tile[c * (TU + 1) + t] = v;
+    }
+    if (!rel_out) return;
+    __syncthreads();
+    float* dst = rel_out + clip * g.Nm * C;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int t = i / C, c = i - t * C;
+        const int64_t m = u0 + t - g.n_wb;
+        if (m >= 0) dst[m * C + c] = tile[c * (TU + 1) + t];
     }
 }
 
@@ -855,7 +738,7 @@ __global__ __launch_bounds__(256) void k_rel_linear(Geom g, float* __restrict__ 
 // does not depend on the hysteresis state.
 struct ScanArgs {
     Geom g;
-    const float* rel;  // [clips][U][C]
+    const float* rel;  // planar [clip*C + c][U]
     const float* thr_mn;
     const float* thr_mx;  // [clips][nb][C] (relative mode)
     const float* on_f;
@@ -870,11 +753,14 @@ struct ScanArgs {
 __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
     const int C = a.g.C, B = a.g.B;
     const int64_t total = a.n_clips * a.nb * C;
-    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
-    const int c = (int)(id % C);
-    const int64_t j = (id / C) % a.nb;
-    const int64_t clip = id / ((int64_t)C * a.nb);
+    // thread order (clip, c, block): neighbouring lanes read neighbouring blocks of one series
+    const int64_t j = id % a.nb;
+    const int64_t chain = id / a.nb;
+    const int c = (int)(chain % C);
+    const int64_t clip = chain / C;
+    const int64_t oi = (clip * a.nb + j) * C + c;
     float on, off;
     double on0;
     if (a.manual) {
@@ -882,27 +768,27 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
         on0 = a.on_d[c];
         off = a.off_f[c];
     } else {
-        float mn = a.thr_mn[id], mx = a.thr_mx[id];
-        float t1 = mx * a.on_f[c];
+        const float mn = a.thr_mn[oi], mx = a.thr_mx[oi];
+        const float t1 = mx * a.on_f[c];
         on = t1 + mn;  // detection.py:763
         on0 = (double)on;
-        float t2 = mx * a.off_f[c];
+        const float t2 = mx * a.off_f[c];
         off = t2 + mn;  // detection.py:787
     }
-    const float* r = a.rel + (clip * a.g.U + a.g.n_wb + j * B) * C + c;
-    // detection.py:769: row 0 compares prev_values (float64 copy of the previous
-    // block's last row; zeros before the first main block) with the threshold
-    float prev = (j == 0) ? 0.0f : r[-C];
+    const float* r = a.rel + chain * a.g.U + a.g.n_wb + j * B;
+    // detection.py:769: row 0 compares prev_values (float64 copy of the previous block's last
+    // row; zeros before the first main block) with the threshold
+    const float prev = (j == 0) ? 0.0f : r[-1];
     bool below_before = (double)prev < on0;
     int first = -1, last = -1;
     for (int t = 0; t < B; ++t) {
-        float v = r[(int64_t)t * C];
+        const float v = r[t];
         if (first < 0 && v > on && below_before) first = t;
         if (v < off) last = t;
         below_before = v < on;
     }
-    a.first_cross[id] = first;
-    a.last_below[id] = last;
+    a.first_cross[oi] = first;
+    a.last_below[oi] = last;
 }
 
 // ---- hysteresis / cooldown state machine over the blocks of one clip
@@ -1037,39 +923,38 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
     if (lane == 0) a.counts[clip] = count;
 }
 
-// ---- backtracking (detection.py:800-825 == envelope_follower.c:59-85), one
-// thread per onset.  The ring buffer of the reference (last N rows after writing
-// the current block) is a window of the main relative envelope; rows before the
-// stream start read as zero.
+// ---- backtracking (detection.py:800-825 == envelope_follower.c:59-85 with the Python loop
+// bound), one thread per onset.  The ring buffer of the reference (last N rows after writing
+// the current block) is a window of the main relative envelope; rows before the stream start
+// or outside the N-row window read as zero.
 struct BtArgs {
     Geom g;
-    const float* rel;  // [clips][U][C]
+    const float* rel;  // planar
     ofp_onset* records;
     const int64_t* counts;
     int64_t cap, n_clips, N;  // N = backtrack_buffer_size
     float alpha, tol;
-    int32_t clip_base;
 };
 
 __device__ __forceinline__ float bt_at(const BtArgs& a, int64_t clip, int64_t block_end, int64_t i, int c) {
-    int64_t m = block_end - i;  // buffer[-i]
-    if (m < 0 || i > a.N) return 0.0f;  // outside the N-row window / before the stream
-    return a.rel[(clip * a.g.U + a.g.n_wb + m) * a.g.C + c];
+    const int64_t m = block_end - i;  // buffer[-i]
+    if (m < 0 || i > a.N) return 0.0f;
+    return a.rel[(clip * a.g.C + c) * a.g.U + a.g.n_wb + m];
 }
 
 __global__ __launch_bounds__(64) void k_backtrack(BtArgs a) {
-    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t clip = id / a.cap, k = id % a.cap;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t clip = id / a.cap, k = id % a.cap;
     if (clip >= a.n_clips) return;
-    int64_t n = min(a.counts[clip], a.cap);
+    const int64_t n = min(a.counts[clip], a.cap);
     if (k >= n) return;
     ofp_onset& r = a.records[clip * a.cap + k];
     const int B = a.g.B;
     const int c = r.channel;
-    int64_t j = r.sample / B;
+    const int64_t j = r.sample / B;
     int64_t delta = r.sample % B;
-    int64_t block_end = (j + 1) * B;
-    float omba = (float)(1.0 - (double)a.alpha);
+    const int64_t block_end = (j + 1) * B;
+    const float omba = (float)(1.0 - (double)a.alpha);
     int64_t i = B - delta;
     float cur = bt_at(a, clip, block_end, i, c);
     i += 1;
@@ -1092,15 +977,16 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R;
-    int64_t o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_pos;
     int64_t ar_L, ar_W, ar_Wc, ar_chunks;
     int64_t mm_L, mm_W, mm_chunks;
+    int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xdb, o_dif, o_hp_state, o_ar_state, o_mm_state, o_thr_mn, o_thr_mx, o_first,
-        o_last, o_flags, total;
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_pos, o_ar_state, o_mm_state,
+        o_thr_mn, o_thr_mx, o_first, o_last, o_flags, total;
 };
 
 int64_t pick(int64_t user, int64_t dflt) { return user > 0 ? user : dflt; }
+int64_t pick_warm(int64_t user, int64_t dflt) { return user > 0 ? user : (user < 0 ? 0 : dflt); }
 
 Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t warm) {
     Layout l;
@@ -1116,32 +1002,30 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     g.V = g.n_w + g.Nm;
     l.nb = g.Nm / g.B;
     // longest follower time constant in samples (coefficient = 1/samples)
-    float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
-    double tau = cmin > 0 ? 1.0 / cmin : 1.0;
-    int64_t ar_w_default = align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024);
-    l.ar_Wc = d->t.ar_coarse_warm > 0 ? d->t.ar_coarse_warm
-                                     : (d->t.ar_coarse_warm < 0 ? 0 : align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
+    const float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
+    const double tau = cmin > 0 ? 1.0 / cmin : 1.0;
     l.hp_L = pick(d->t.hp_chunk, 8192);
-    l.hp_W = d->t.hp_warm > 0 ? d->t.hp_warm : (d->t.hp_warm < 0 ? 0 : 49152);
+    l.hp_W = pick_warm(d->t.hp_warm, 49152);
     l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, 8)));
     l.hp_delta = pick(d->t.hp_candidate_offset, 1021);
     l.ar_L = pick(d->t.ar_chunk, 4096);
-    l.ar_W = d->t.ar_warm > 0 ? d->t.ar_warm : (d->t.ar_warm < 0 ? 0 : ar_w_default);
+    l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
+    l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
     l.mm_L = pick(d->t.mm_chunk, 8192);
-    l.mm_W = d->t.mm_warm > 0 ? d->t.mm_warm : (d->t.mm_warm < 0 ? 0 : 49152);
+    l.mm_W = pick_warm(d->t.mm_warm, 32768);
     l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
     l.ar_chunks = std::max<int64_t>(1, cdiv(g.U, l.ar_L));
     l.mm_chunks = std::max<int64_t>(1, cdiv(g.U, l.mm_L));
+    l.tu = (int)std::max<int64_t>(1, std::min<int64_t>(256, 8192 / g.C));
     int64_t o = 0;
     auto take = [&](int64_t bytes) {
         int64_t r = o;
         o += align_up(bytes, 256);
         return r;
     };
-    const int64_t stream = n_clips * g.U * g.C * 4;
-    l.o_xdb = take(stream);
-    l.o_dif = take(stream);
-    l.o_hp_state = take(256);
+    l.o_xt = take(n_clips * g.C * N * 4 + 64);
+    l.o_xdb = take(n_clips * g.C * g.U * 4 + 64);
+    l.o_dif = take(n_clips * g.C * g.U * 4 + 64);
     {
         const int64_t cc = n_clips * l.hp_chunks * g.C;
         l.o_hp_U = take(cc * (l.hp_R + 1) * 16);
@@ -1162,64 +1046,36 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     return l;
 }
 
-// chunk-Jacobi driver for one stage; returns OFP_OK or an error
-template <class S>
-int launch_pass(const char* name, const S& st, int pass, int64_t n_threads, const uint32_t* prev, uint32_t* next,
-                uint32_t* used, int* d_changed, hipStream_t stream) {
-    const unsigned grid = (unsigned)cdiv(n_threads, 64);
-    hipLaunchKernelGGL(k_jacobi<S>, dim3(grid), dim3(64), 0, stream, st, pass, n_threads, prev, next, used,
-                       d_changed);
-    OFP_LAUNCH_CHECK(name);
-    return OFP_OK;
-}
-
-template <>
-int launch_pass<HpStage>(const char* name, const HpStage& st, int pass, int64_t n_threads, const uint32_t* prev,
-                         uint32_t* next, uint32_t* used, int* d_changed, hipStream_t stream) {
-    const int64_t n4 = n_threads * 4;  // four lanes per chain
-    hipLaunchKernelGGL(k_jacobi_hp4, dim3((unsigned)cdiv(n4, 64)), dim3(64), 0, stream, st, pass, n4, prev, next,
-                       used, d_changed);
-    OFP_LAUNCH_CHECK(name);
-    return OFP_OK;
-}
-
-// d_changed: int[OFP_MAX_GROUP]; passes are launched in groups of `group` between host
-// synchronisations (a converged stage makes the surplus passes of a group no-ops).
-constexpr int OFP_MAX_GROUP = 16;
-
-template <class S>
-int run_stage(const char* name, S st, int64_t n_clips, unsigned char* ws, int64_t o_state,
-              int* d_changed, int group, int max_passes, hipStream_t stream, int64_t* passes,
-              int64_t* repaired) {
-    const int64_t n_threads = n_clips * st.n_chunks * st.g.C;
-    const int64_t words = n_threads * S::NS;
-    uint32_t* used = reinterpret_cast<uint32_t*>(ws + o_state);
+// chunk-Jacobi driver: `chunk` kernel pass 0 (from used[]), then verification/repair passes
+// until a pass changes nothing.  used[] has been filled by the stage's warm-up kernels.
+template <class K, class A>
+int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
+               int* d_changed, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
+    const int64_t words = n_threads * 2;
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
-    int rc = launch_pass(name, st, 0, n_threads, (const uint32_t*)endB, endA, used, d_changed, stream);
-    if (rc != OFP_OK) return rc;
+    const unsigned grid = (unsigned)cdiv(n_threads, 64);
+    hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
+                       d_changed);
+    OFP_LAUNCH_CHECK(name);
     *passes = 1;
-    if (st.n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
+    if (n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
     uint32_t* prev = endA;
     uint32_t* next = endB;
-    group = std::max(1, std::min(group, OFP_MAX_GROUP));
-    for (int pass = 1;;) {
-        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int) * OFP_MAX_GROUP, stream));
-        for (int gidx = 0; gidx < group; ++gidx, ++pass) {
-            rc = launch_pass(name, st, pass, n_threads, (const uint32_t*)prev, next, used,
-                             d_changed + gidx, stream);
-            if (rc != OFP_OK) return rc;
-            std::swap(prev, next);
-            *passes += 1;
-        }
-        int changed[OFP_MAX_GROUP];
-        OFP_HIP(hipMemcpyAsync(changed, d_changed, sizeof(int) * group, hipMemcpyDeviceToHost, stream));
+    for (int pass = 1;; ++pass) {
+        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass, n_threads, (const uint32_t*)prev, next,
+                           used, d_changed);
+        OFP_LAUNCH_CHECK(name);
+        int changed = 0;
+        OFP_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
         OFP_HIP(hipStreamSynchronize(stream));
-        for (int gidx = 0; gidx < group; ++gidx) *repaired += changed[gidx];
-        if (changed[group - 1] == 0) break;
-        if (max_passes > 0 && pass > max_passes)
-            return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name,
-                             changed[group - 1], pass - 1);
+        std::swap(prev, next);
+        *passes += 1;
+        *repaired += changed;
+        if (changed == 0) break;
+        if (max_passes > 0 && pass >= max_passes)
+            return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name, changed, pass);
     }
     return OFP_OK;
 }
@@ -1302,6 +1158,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     OFP_REQUIRE(n_clips >= 1 && N >= 0 && cap >= 0, "ofp_detect_offline: bad sizes");
     OFP_REQUIRE(d_x || N == 0, "ofp_detect_offline: d_x is NULL");
     OFP_REQUIRE(d_records || cap == 0, "ofp_detect_offline: d_records is NULL");
+    OFP_REQUIRE(n_clips <= 65535, "ofp_detect_offline: at most 65535 clips per call");
     hipStream_t stream = (hipStream_t)stream_;
     const Layout l = make_layout(d, n_clips, N, warm);
     if (ws_bytes < l.total)
@@ -1310,6 +1167,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const Geom& g = l.g;
     const auto& p = d->p;
     unsigned char* ws = static_cast<unsigned char*>(d_ws);
+    float* xt = reinterpret_cast<float*>(ws + l.o_xt);
     float* xdb = reinterpret_cast<float*>(ws + l.o_xdb);
     float* dif = reinterpret_cast<float*>(ws + l.o_dif);
     int* d_changed = reinterpret_cast<int*>(ws + l.o_flags);
@@ -1322,22 +1180,27 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (h_info) std::memcpy(h_info, info, sizeof(info));
         return OFP_OK;
     }
-    const int64_t n_elem = n_clips * g.U * g.C;
+    const int64_t chains = n_clips * g.C;
+    const int64_t n_elem = chains * g.U;
     const unsigned ew_grid = (unsigned)std::min<int64_t>(cdiv(n_elem, 256), 256 * 16);
+    const size_t tile_lds = (size_t)g.C * (l.tu + 1) * sizeof(float);
+
+    // --- transpose in
+    hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds, stream,
+                       d_x, xt, N, g.C, l.tu);
+    OFP_LAUNCH_CHECK("k_transpose_in");
 
     // --- hp + dB
     if (p.hp_enabled) {
-        HpStage st;
-        st.g = g;
-        st.x = d_x;
-        st.out = xdb;
-        std::memcpy(st.b, d->b, sizeof(st.b));
-        std::memcpy(st.a, d->a, sizeof(st.a));
-        st.L = l.hp_L;
-        st.W = l.hp_W;
-        st.n_chunks = l.hp_chunks;
         HpCand hc;
-        hc.st = st;
+        hc.st.g = g;
+        hc.st.xt = xt;
+        hc.st.out = xdb;
+        std::memcpy(hc.st.b, d->b, sizeof(hc.st.b));
+        std::memcpy(hc.st.a, d->a, sizeof(hc.st.a));
+        hc.st.L = l.hp_L;
+        hc.st.W = l.hp_W;
+        hc.st.n_chunks = l.hp_chunks;
         hc.R = l.hp_R;
         hc.delta = l.hp_delta;
         hc.U = reinterpret_cast<uint32_t*>(ws + l.o_hp_U);
@@ -1347,13 +1210,12 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
-        OFP_HIP(hipMemsetAsync(hc.pos, 0, n_clips * g.C * 4, stream));
-        const int64_t chains = n_clips * g.C;
-        const int64_t nA = n_clips * l.hp_chunks * g.C * hc.R * 4;
-        const int64_t nM = n_clips * l.hp_chunks * g.C * (hc.R + 1);
-        const int64_t nC = n_clips * l.hp_chunks * g.C * 4;
-        hipLaunchKernelGGL(k_hp_candidates1, dim3((unsigned)cdiv(nA / 4, 64)), dim3(64), 0, stream, hc, nA / 4);
-        OFP_LAUNCH_CHECK("k_hp_candidates1");
+        OFP_HIP(hipMemsetAsync(hc.pos, 0, chains * 4, stream));
+        const int64_t nA = chains * l.hp_chunks * hc.R;
+        const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
+        const int64_t nC = chains * l.hp_chunks;
+        hipLaunchKernelGGL(k_hp_candidates, dim3((unsigned)cdiv(nA, 64)), dim3(64), 0, stream, hc, nA);
+        OFP_LAUNCH_CHECK("k_hp_candidates");
         for (int it = 0;; ++it) {
             OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
             hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
@@ -1373,34 +1235,41 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
     }
     OFP_HIP(hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, d_x, xdb, n_clips,
-                       p.hp_enabled ? 0 : 1, p.floor_db);
+    hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, xt, xdb, chains, p.hp_enabled ? 0 : 1,
+                       p.floor_db);
     OFP_LAUNCH_CHECK("k_rect_db");
     OFP_HIP(hipEventRecord(ev[2], stream));
 
     // --- followers
     {
-        ArStage st;
-        st.g = g;
-        st.xdb = xdb;
-        st.dif = dif;
-        st.fa = p.fast_attack;
-        st.fr = p.fast_release;
-        st.sa = p.slow_attack;
-        st.sr = p.slow_release;
-        st.floor_db = p.floor_db;
-        st.L = l.ar_L;
-        st.W = l.ar_W;
-        st.Wc = l.ar_Wc;
-        st.n_chunks = l.ar_chunks;
-        int rc = run_stage("follower stage", st, n_clips, ws, l.o_ar_state, d_changed, 1,
-                           d->t.max_passes, stream, &info[1], &info[3]);
+        ArArgs a;
+        a.g = g;
+        a.xdb = xdb;
+        a.dif = dif;
+        a.fa = p.fast_attack;
+        a.fr = p.fast_release;
+        a.sa = p.slow_attack;
+        a.sr = p.slow_release;
+        a.floor_db = p.floor_db;
+        a.L = l.ar_L;
+        a.W = l.ar_W;
+        a.Wc = l.ar_Wc;
+        a.n_chunks = l.ar_chunks;
+        const int64_t nt = chains * l.ar_chunks;
+        uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
+        const unsigned grid = (unsigned)cdiv(nt, 64);
+        hipLaunchKernelGGL(k_ar_coarse, dim3(grid), dim3(64), 0, stream, a, nt, used);
+        OFP_LAUNCH_CHECK("k_ar_coarse");
+        hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
+        OFP_LAUNCH_CHECK("k_ar_warm");
+        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, d_changed, d->t.max_passes,
+                            stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
     OFP_HIP(hipEventRecord(ev[3], stream));
-    hipLaunchKernelGGL(k_rel_linear, dim3(ew_grid), dim3(256), 0, stream, g, dif, d_rel, n_clips,
-                       p.floor_db);
-    OFP_LAUNCH_CHECK("k_rel_linear");
+    hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), tile_lds, stream, g,
+                       dif, d_rel, p.floor_db, l.tu);
+    OFP_LAUNCH_CHECK("k_rel_out");
     OFP_HIP(hipEventRecord(ev[4], stream));
     const float* rel = dif;
 
@@ -1408,28 +1277,35 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     float* thr_mn = reinterpret_cast<float*>(ws + l.o_thr_mn);
     float* thr_mx = reinterpret_cast<float*>(ws + l.o_thr_mx);
     if (!p.manual) {
-        MmStage st;
-        st.g = g;
-        st.rel = rel;
-        st.thr_mn = thr_mn;
-        st.thr_mx = thr_mx;
-        st.alpha_min = p.alpha_min;
-        st.alpha_max = p.alpha_max;
-        st.ialpha_min = d->ialpha_min;
-        st.ialpha_max = d->ialpha_max;
-        st.minmin = p.minmin;
-        st.min0 = p.min0;
-        st.max0 = p.max0;
-        st.nb = l.nb;
-        st.L = l.mm_L;
-        st.W = l.mm_W;
-        st.n_chunks = l.mm_chunks;
-        int rc = run_stage("tracker stage", st, n_clips, ws, l.o_mm_state, d_changed, 1,
-                           d->t.max_passes, stream, &info[2], &info[3]);
+        MmArgs a;
+        a.g = g;
+        a.rel = rel;
+        a.thr_mn = thr_mn;
+        a.thr_mx = thr_mx;
+        a.alpha_min = p.alpha_min;
+        a.alpha_max = p.alpha_max;
+        a.ialpha_min = d->ialpha_min;
+        a.ialpha_max = d->ialpha_max;
+        a.minmin = p.minmin;
+        a.min0 = p.min0;
+        a.max0 = p.max0;
+        a.nb = l.nb;
+        a.L = l.mm_L;
+        a.W = l.mm_W;
+        a.n_chunks = l.mm_chunks;
+        const int64_t nt = chains * l.mm_chunks;
+        uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
+        const unsigned grid = (unsigned)cdiv(nt, 64);
+        hipLaunchKernelGGL(k_mm_max, dim3(grid), dim3(64), 0, stream, a, nt, used);
+        OFP_LAUNCH_CHECK("k_mm_max");
+        hipLaunchKernelGGL(k_mm_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
+        OFP_LAUNCH_CHECK("k_mm_warm");
+        int rc = run_jacobi("tracker stage", k_mm_chunk, a, nt, l.mm_chunks, used, d_changed, d->t.max_passes, stream,
+                            &info[2], &info[3]);
         if (rc != OFP_OK) return rc;
     }
-
     OFP_HIP(hipEventRecord(ev[5], stream));
+
     // --- crossings per block, then the hysteresis state machine
     ScanArgs sa;
     sa.g = g;
@@ -1445,7 +1321,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sa.first_cross = reinterpret_cast<int32_t*>(ws + l.o_first);
     sa.last_below = reinterpret_cast<int32_t*>(ws + l.o_last);
     {
-        int64_t total = n_clips * l.nb * g.C;
+        const int64_t total = n_clips * l.nb * g.C;
         hipLaunchKernelGGL(k_block_scan, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, sa);
         OFP_LAUNCH_CHECK("k_block_scan");
     }
@@ -1480,7 +1356,6 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         bt.N = p.backtrack_buffer_size;
         bt.alpha = p.backtrack_alpha;
         bt.tol = p.backtrack_tol;
-        bt.clip_base = 0;
         hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
         OFP_LAUNCH_CHECK("k_backtrack");
     }
