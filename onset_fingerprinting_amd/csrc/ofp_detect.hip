@@ -890,7 +890,18 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
                 mx = max(mx, oi);
             }
             // :790 on_indices.max() over ALL channels
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+            // (lanes without an onset hold 0; onsets are sparse, so read the firing lanes'
+            // values one by one through scalar readlane instead of a six-step LDS shuffle tree)
+            {
+                unsigned long long fm = __ballot(mx > 0);
+                int red = 0;
+                while (fm) {
+                    const int l = __builtin_ctzll(fm);
+                    red = max(red, __builtin_amdgcn_readlane(mx, l));
+                    fm &= fm - 1;
+                }
+                mx = red;
+            }
             bool latched = false;
             for (int c0 = 0; c0 < C; c0 += 64) {
                 int c = c0 + lane;
@@ -1119,7 +1130,7 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_on_f, onf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
-    for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
+    for (int k = 0; k < 10 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
     if (e != hipSuccess) {
         ofp_detector_destroy(d);
         return ofp::fail(OFP_ERR_HIP, "ofp_detector_create: %s", hipGetErrorString(e));
@@ -1133,7 +1144,7 @@ int ofp_detector_destroy(ofp_detector* d) {
     if (d->d_on_f) (void)hipFree(d->d_on_f);
     if (d->d_off_f) (void)hipFree(d->d_off_f);
     if (d->d_on_d) (void)hipFree(d->d_on_d);
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 10; ++k)
         if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     delete d;
     return OFP_OK;
@@ -1174,6 +1185,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     int64_t info[OFP_DETECT_INFO_LEN] = {0};
     hipEvent_t* ev = d->ev;
     OFP_HIP(hipEventRecord(ev[0], stream));
+    bool hp_cand_timed = false;
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
         OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
         OFP_HIP(hipStreamSynchronize(stream));
@@ -1189,6 +1201,7 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds, stream,
                        d_x, xt, N, g.C, l.tu);
     OFP_LAUNCH_CHECK("k_transpose_in");
+    OFP_HIP(hipEventRecord(ev[8], stream));
 
     // --- hp + dB
     if (p.hp_enabled) {
@@ -1216,6 +1229,8 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nC = chains * l.hp_chunks;
         hipLaunchKernelGGL(k_hp_candidates, dim3((unsigned)cdiv(nA, 64)), dim3(64), 0, stream, hc, nA);
         OFP_LAUNCH_CHECK("k_hp_candidates");
+        OFP_HIP(hipEventRecord(ev[7], stream));
+        hp_cand_timed = true;
         for (int it = 0;; ++it) {
             OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
             hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
@@ -1371,6 +1386,11 @@ int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         float ms = 0.0f;
         OFP_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
         info[10] = (int64_t)(ms * 1.0e6);
+    }
+    if (hp_cand_timed) {  // the single longest launch: k_hp_candidates
+        float ms = 0.0f;
+        OFP_HIP(hipEventElapsedTime(&ms, ev[8], ev[7]));
+        info[11] = (int64_t)(ms * 1.0e6);
     }
     if (h_info) std::memcpy(h_info, info, sizeof(info));
     return OFP_OK;

@@ -13,5 +13,5 @@ struct ofp_detector {
     float* d_off_f = nullptr;  // [C]
     double* d_on_d = nullptr;  // [C] the Python double, used for row 0 in manual mode
     ofp_detect_tuning t;
-    hipEvent_t ev[8] = {};     // stage timing (ofp_detect_offline h_info)
+    hipEvent_t ev[10] = {};     // stage timing (ofp_detect_offline h_info)
 };

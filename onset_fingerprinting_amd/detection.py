@@ -156,7 +156,8 @@ class BatchDetector:
             hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3],
             # stage durations, HIP events on the launch stream (milliseconds)
             stage_ms=dict(hp=info[4] / 1e6, db=info[5] / 1e6, ar=info[6] / 1e6, rel=info[7] / 1e6,
-                          mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6))
+                          mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6,
+                          hp_candidates=info[11] / 1e6))
         out["cap"] = cap
         return out
 
