@@ -62,6 +62,12 @@ void minmax_envelope(float* x, float* min_val, float* max_val, float alpha_min, 
 void backtrack_onsets(float* buffer, long* channels, long* deltas, float alpha, float tol,
                       long buffer_length, long n_onsets, long n_channels, long block_size);
 
+/* ButterworthFilter.__call__ (detection.py:499-501): scipy.signal.lfilter(b, a, x, axis=0, zi) in
+ * float32 (direct form II transposed, coefficients normalised by a[0] in fp32), HOST pointers like
+ * the legacy symbols: x,y [n][n_channels]; b,a [order+1]; zi [order][n_channels] in/out; order <= 8 */
+int ofp_lfilter(const float* x, float* y, const float* b, const float* a, int order, float* zi, long n,
+                int n_channels);
+
 /* ---- amplitude onset detector (detection.py:595-888) ----------------------------- */
 typedef struct ofp_detector_params {
     int32_t n_channels;   /* C: signals per detector instance (detection.py:633) */

@@ -69,6 +69,8 @@ SIGNATURES = {
     "minmax_envelope": (None, [_f32p_h, _f32p_h, _f32p_h, _f32, _f32, _f32, ctypes.c_int, ctypes.c_int]),
     "backtrack_onsets": (None, [_f32p_h, _long_p, _long_p, _f32, _f32, ctypes.c_long, ctypes.c_long,
                                 ctypes.c_long, ctypes.c_long]),
+    "ofp_lfilter": (ctypes.c_int, [_f32p_h, _f32p_h, _f32p_h, _f32p_h, ctypes.c_int, _f32p_h, ctypes.c_long,
+                                   ctypes.c_int]),
     "ofp_detector_create": (ctypes.c_int, [ctypes.POINTER(DetectorParams), ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_vp)]),
     "ofp_detector_destroy": (ctypes.c_int, [_vp]),

@@ -81,6 +81,42 @@ __global__ __launch_bounds__(64) void k_legacy_backtrack(const float* __restrict
     deltas[j] = delta;
 }
 
+// scipy.signal.lfilter(b, a, x, axis=0, zi) in float32, direct form II transposed, any order
+// <= 8 (detection.py:487-501); one thread per channel; b,a are normalised by a[0] in fp32 first
+constexpr int LF_MAX = 8;
+struct LfArgs {
+    const float* x;
+    float* y;
+    float* zi;  // [order][C]
+    float b[LF_MAX + 1], a[LF_MAX + 1];
+    int order, C;
+    long n;
+};
+__global__ __launch_bounds__(64) void k_lfilter(LfArgs p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    float z[LF_MAX];
+    for (int k = 0; k < LF_MAX; ++k) z[k] = k < p.order ? p.zi[k * p.C + c] : 0.0f;
+    for (long t = 0; t < p.n; ++t) {
+        const float xv = p.x[t * p.C + c];
+        float yv;
+        if (p.order == 0) {
+            yv = xv * p.b[0];
+        } else {
+            yv = z[0] + p.b[0] * xv;
+#pragma unroll
+            for (int k = 0; k < LF_MAX - 1; ++k)
+                if (k < p.order - 1) z[k] = (z[k + 1] + xv * p.b[k + 1]) - yv * p.a[k + 1];
+#pragma unroll
+            for (int k = 0; k < LF_MAX; ++k)
+                if (k == p.order - 1) z[k] = xv * p.b[k + 1] - yv * p.a[k + 1];
+        }
+        p.y[t * p.C + c] = yv;
+    }
+    for (int k = 0; k < LF_MAX; ++k)
+        if (k < p.order) p.zi[k * p.C + c] = z[k];
+}
+
 struct DevBuf {
     void* p = nullptr;
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
@@ -127,6 +163,37 @@ int ofp_device_check(int device, char* buf, int buflen) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return ofp::fail(OFP_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device,
                          prop.gcnArchName);
+    return OFP_OK;
+}
+
+int ofp_lfilter(const float* x, float* y, const float* b, const float* a, int order, float* zi, long n,
+                int n_channels) {
+    OFP_REQUIRE(x && y && b && a && (zi || order == 0), "ofp_lfilter: NULL argument");
+    OFP_REQUIRE(order >= 0 && order <= LF_MAX, "ofp_lfilter: order %d not in [0, %d]", order, LF_MAX);
+    OFP_REQUIRE(a[0] != 0.0f, "ofp_lfilter: a[0] must be non-zero");
+    if (n <= 0 || n_channels <= 0) return OFP_OK;
+    const size_t bytes = (size_t)n * n_channels * sizeof(float), zb = (size_t)order * n_channels * sizeof(float);
+    DevBuf dx, dy, dz;
+    OFP_HIP(dx.alloc(bytes));
+    OFP_HIP(dy.alloc(bytes));
+    OFP_HIP(dz.alloc(zb));
+    OFP_HIP(hipMemcpy(dx.p, x, bytes, hipMemcpyHostToDevice));
+    if (zb) OFP_HIP(hipMemcpy(dz.p, zi, zb, hipMemcpyHostToDevice));
+    LfArgs p;
+    p.x = (const float*)dx.p;
+    p.y = (float*)dy.p;
+    p.zi = (float*)dz.p;
+    p.order = order;
+    p.C = n_channels;
+    p.n = n;
+    for (int k = 0; k <= LF_MAX; ++k) {
+        p.b[k] = k <= order ? b[k] / a[0] : 0.0f;
+        p.a[k] = k <= order ? a[k] / a[0] : 0.0f;
+    }
+    hipLaunchKernelGGL(k_lfilter, dim3((n_channels + 63) / 64), dim3(64), 0, 0, p);
+    OFP_LAUNCH_CHECK("k_lfilter");
+    OFP_HIP(hipMemcpy(y, dy.p, bytes, hipMemcpyDeviceToHost));
+    if (zb) OFP_HIP(hipMemcpy(zi, dz.p, zb, hipMemcpyDeviceToHost));
     return OFP_OK;
 }
 

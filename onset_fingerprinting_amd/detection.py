@@ -296,3 +296,78 @@ class AmplitudeOnsetDetector:
             self.d.handle, self._state.data_ptr(), xd.data_ptr(), 0, x.shape[0], 1, 0, None, None, 0, None,
             _stream_ptr(xd.device)), "ofp_stream_process(warmup)")
         torch.cuda.current_stream(xd.device).synchronize()
+
+
+_FP = ctypes.POINTER(ctypes.c_float)
+
+
+def _f32_block(x, what):
+    """The reference's ctypes ``ndpointer(float32, ndim=2, C_CONTIGUOUS)`` check
+    (detection.py:520-531, 563-578): wrong dtype / layout raises ctypes.ArgumentError."""
+    if not isinstance(x, np.ndarray) or x.dtype != np.float32 or x.ndim != 2 or not x.flags["C_CONTIGUOUS"]:
+        raise ctypes.ArgumentError(f"{what}: array must be a C-contiguous 2-D float32 ndarray")
+    return x
+
+
+class ButterworthFilter:
+    """Butterworth filter applied to multiple signals in parallel (detection.py:487-501):
+    scipy design, float32 coefficients and state, ``lfilter`` semantics; the filtering runs
+    on the GPU (``ofp_lfilter``, direct form II transposed in fp32, bit-identical to scipy)."""
+
+    def __init__(self, cutoff, n, order=2, sr=44100, btype="high"):
+        if order > 8:
+            raise ValueError("order > 8 is not supported by the GPU filter")
+        self.b, self.a = sig.butter(order, cutoff, btype=btype, analog=False, output="ba", fs=sr)
+        self.b, self.a = np.float32(self.b), np.float32(self.a)
+        self.zi = np.zeros((order, n), dtype=np.float32)
+        self._lib = _lib.lib()
+        _lib.require_gpu(0)
+
+    def __call__(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        check(self._lib.ofp_lfilter(x.ctypes.data_as(_FP), y.ctypes.data_as(_FP), self.b.ctypes.data_as(_FP),
+                                    self.a.ctypes.data_as(_FP), len(self.b) - 1, self.zi.ctypes.data_as(_FP),
+                                    x.shape[0], x.shape[1]), "ofp_lfilter")
+        return y
+
+
+class AREnvelopeFollower:
+    """Attack-release envelope follower for several signals at once (detection.py:504-538),
+    through the drop-in ``ar_envelope`` symbol of libonsetfp.so."""
+
+    def __init__(self, x0: np.ndarray, attack=3, release=383):
+        self.attack = np.float32(1 / attack)
+        self.release = np.float32(1 / release)
+        self.y = np.ascontiguousarray(x0, dtype=np.float32).copy()
+        self.c_ar_env = _lib.lib()
+        _lib.require_gpu(0)
+        self.n, self.size = np.int32(x0.shape)
+
+    def __call__(self, x):
+        _f32_block(x, "ar_envelope")
+        self.c_ar_env.ar_envelope(x.ctypes.data_as(_FP), self.y.ctypes.data_as(_FP), self.attack, self.release,
+                                  int(self.size), int(self.n))
+        return self.y  # the same state array object every call (detection.py:538)
+
+
+class MinMaxEnvelopeFollower:
+    """EMA min/max tracker for multi-channel signals (detection.py:541-592), through the
+    drop-in ``minmax_envelope`` symbol of libonsetfp.so."""
+
+    def __init__(self, x0: np.ndarray, alpha_min=1e-5, alpha_max=1e-5, minmin=0.0):
+        self.alpha_min = np.float32(alpha_min)
+        self.alpha_max = np.float32(alpha_max)
+        self.minmin = np.float32(minmin)
+        self.min_val = np.float32(np.min(x0, axis=0))
+        self.max_val = np.float32(np.max(x0, axis=0))
+        self.c_tracker = _lib.lib()
+        _lib.require_gpu(0)
+        self.n_samples, self.n_channels = np.int32(x0.shape)
+
+    def __call__(self, x):
+        _f32_block(x, "minmax_envelope")
+        self.c_tracker.minmax_envelope(x.ctypes.data_as(_FP), self.min_val.ctypes.data_as(_FP),
+                                       self.max_val.ctypes.data_as(_FP), self.alpha_min, self.alpha_max,
+                                       self.minmin, len(x), int(self.n_channels))
+        return self.min_val, self.max_val

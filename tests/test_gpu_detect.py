@@ -197,3 +197,38 @@ def test_error_behaviour(det):
         det.AmplitudeOnsetDetector(2, 32)(np.zeros((32, 2), np.float64))
     with pytest.raises(AssertionError):
         det.AmplitudeOnsetDetector(2, 128, backtrack=True, backtrack_buffer_size=64)
+
+
+def test_follower_and_filter_classes_match_reference_goldens(det):
+    """AREnvelopeFollower / MinMaxEnvelopeFollower / ButterworthFilter: the reference's
+    callable surface (detection.py:487-592), bit-for-bit against goldens g1, g2, g11."""
+    g = load_golden("g1_ar_envelope")
+    x = g["x"]
+    for k, (a, r) in enumerate(g["pairs"][:2]):
+        f = det.AREnvelopeFollower(np.full((64, x.shape[1]), -70.0, dtype=np.float32), a, r)
+        ys = [f(np.ascontiguousarray(x[i:i + 64])).copy() for i in range(0, len(x), 64)]
+        assert np.array_equal(bits(np.concatenate(ys)), bits(g[f"y{k}"]))
+        assert f(np.ascontiguousarray(x[:64])) is f.y
+    g2 = load_golden("g2_minmax")
+    mm = det.MinMaxEnvelopeFollower(x0=np.array([[0, 10]] * 8).T, alpha_min=1e-4, alpha_max=1e-5, minmin=2)
+    B2 = int(g2["B"])
+    for i in range(0, len(g2["x"]), B2):
+        mi, ma = mm(np.ascontiguousarray(g2["x"][i:i + B2]))
+        assert np.array_equal(bits(mi), bits(g2["mins"][i // B2])) and np.array_equal(bits(ma), bits(g2["maxs"][i // B2]))
+    with pytest.raises(ctypes.ArgumentError):
+        mm(np.zeros((B2, 8), np.float64))
+    g11 = load_golden("g11_lfilter")
+    for k in range(3):
+        cut, sr = g11[f"cfg{k}"]
+        f = det.ButterworthFilter(cut, 3, 4, int(sr), "high")
+        assert np.array_equal(f.b, g11[f"b{k}"]) and np.array_equal(f.a, g11[f"a{k}"])
+        ys = [f(g11["x"][i:i + 500]) for i in range(0, 3000, 500)]
+        assert np.array_equal(bits(np.concatenate(ys)), bits(g11[f"y{k}"]))
+        assert np.array_equal(bits(f.zi), bits(g11[f"zi{k}"]))
+    # default order 2 (detection.py:490) against scipy itself
+    from scipy import signal as sig
+    f2 = det.ButterworthFilter(1500.0, 3, sr=48000)
+    y2 = f2(g11["x"])
+    b, a = sig.butter(2, 1500.0, btype="high", fs=48000)
+    ref, _ = sig.lfilter(np.float32(b), np.float32(a), g11["x"], axis=0, zi=np.zeros((2, 3), np.float32))
+    assert np.array_equal(bits(y2), bits(ref))
