@@ -223,6 +223,10 @@ int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float*
                const float* d_b, int32_t cout, int32_t k, int32_t padding, int32_t dilation,
                int32_t act, float* d_y, void* stream);
 
+/* CCCNN correlation head (model.py:524-534): d_x [n][K][V] feature maps -> d_out [n][2V-1]:
+ * full auto-correlation of every map, summed over the K maps, soft-maxed over the lags. */
+int ofp_autocorr_softmax(const float* d_x, int64_t n, int32_t K, int32_t V, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

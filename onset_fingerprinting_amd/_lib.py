@@ -88,6 +88,7 @@ SIGNATURES = {
     "ofp_mel": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofp_mfcc": (ctypes.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "ofp_dense": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
 

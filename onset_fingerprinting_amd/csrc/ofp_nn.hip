@@ -89,9 +89,70 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
     }
 }
 
+// CCCNN correlation head (model.py:524-534): for each item (b, c) the K feature maps [K][V] are
+// auto-correlated (full, 2V-1 lags: cc[j] = sum_i f[i + j - (V-1)] * f[i]), summed over the maps
+// and soft-maxed over the lags.  One workgroup per item; the maps live in LDS.
+__global__ __launch_bounds__(256) void k_autocorr_softmax(const float* __restrict__ x, int K, int V,
+                                                          float* __restrict__ out) {
+    extern __shared__ float sm[];  // [K*V] maps, then [2V-1] cc, then 64 scratch
+    const int64_t item = blockIdx.x;
+    const int L = 2 * V - 1;
+    float* f = sm;
+    float* cc = sm + (size_t)K * V;
+    float* red = cc + L;
+    const float* src = x + item * (int64_t)K * V;
+    for (int i = threadIdx.x; i < K * V; i += blockDim.x) f[i] = src[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        const int sh = j - (V - 1);  // lag
+        const int lo = sh < 0 ? -sh : 0, hi = sh > 0 ? V - sh : V;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float* fk = f + k * V;
+            for (int i = lo; i < hi; ++i) acc = fmaf(fk[i + sh], fk[i], acc);
+        }
+        cc[j] = acc;
+    }
+    __syncthreads();
+    // softmax over the L lags
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < L; j += blockDim.x) m = fmaxf(m, cc[j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float ssum = 0.0f;
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        const float e = expf(cc[j] - m);
+        cc[j] = e;
+        ssum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssum;
+    __syncthreads();
+    ssum = red[0] + red[1] + red[2] + red[3];
+    float* dst = out + item * (int64_t)L;
+    for (int j = threadIdx.x; j < L; j += blockDim.x) dst[j] = cc[j] / ssum;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ofp_autocorr_softmax(const float* d_x, int64_t n, int32_t K, int32_t V, float* d_out, void* stream) {
+    if (n == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_out && K >= 1 && V >= 1, "ofp_autocorr_softmax: bad argument");
+    const size_t lds = ((size_t)K * V + 2 * V + 64) * sizeof(float);
+    OFP_REQUIRE(lds <= 160 * 1024, "ofp_autocorr_softmax: K*V = %d floats do not fit the LDS", K * V);
+    if (lds > 65536)
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_autocorr_softmax),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_autocorr_softmax, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, d_x, K, V, d_out);
+    OFP_LAUNCH_CHECK("k_autocorr_softmax");
+    return OFP_OK;
+}
+
 
 int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float* d_w, const float* d_b,
               const float* d_scale, const float* d_shift, int32_t act, float* d_y, void* stream) {

@@ -34,4 +34,4 @@ from .spectral import (  # noqa: F401
     stft_frame,
     window_contribution_weights,
 )
-from .classifier import cnn_forward, fcnn_forward  # noqa: F401
+from .classifier import cccnn_forward, cnn_forward, fcnn_forward  # noqa: F401

@@ -65,3 +65,36 @@ def cnn_forward(sd, x, padding=1, dilation=1, activation="silu"):
         i += 1
     x = x.reshape(x.shape[0], -1)
     return x @ sd["fc.weight"].astype(np.float64).T + sd["fc.bias"].astype(np.float64)
+
+
+def cccnn_forward(sd, x, padding=1, dilation=1, activation="silu"):
+    """model.py:443-538 (group=False, no batch_norm / pool, stride 1) in eval mode:
+    shared 1-input-channel conv stack per sensor channel -> full auto-correlation of every
+    feature map (F.conv1d(x, x, groups, padding=V-1)) summed over the maps -> softmax over
+    the lags -> flatten -> Linear.  x [B, C, W] -> [B, out].  fp64 arithmetic."""
+    x = np.asarray(x, dtype=np.float64)
+    B, C, W = x.shape
+    act = _ACT[activation]
+    h = x.reshape(B * C, 1, W)
+    i = 1
+    while f"conv_layers.conv{i}.weight" in sd:
+        Wt = sd[f"conv_layers.conv{i}.weight"].astype(np.float64)  # [O, I, K]
+        b = sd[f"conv_layers.conv{i}.bias"].astype(np.float64)
+        O, I, K = Wt.shape
+        n, _, L = h.shape
+        hp = np.pad(h, ((0, 0), (0, 0), (padding, padding)))
+        Lout = L + 2 * padding - dilation * (K - 1)
+        y = np.zeros((n, O, Lout))
+        for k in range(K):
+            y += np.einsum("bil,oi->bol", hp[:, :, k * dilation: k * dilation + Lout], Wt[:, :, k])
+        h = act(y + b[None, :, None])
+        i += 1
+    n, K, V = h.shape
+    cc = np.zeros((n, 2 * V - 1))
+    for j in range(2 * V - 1):
+        sh = j - (V - 1)
+        lo, hi = max(0, -sh), min(V, V - sh)
+        cc[:, j] = (h[:, :, lo + sh: hi + sh] * h[:, :, lo:hi]).sum(axis=(1, 2))
+    e = np.exp(cc - cc.max(axis=1, keepdims=True))
+    probs = (e / e.sum(axis=1, keepdims=True)).reshape(B, -1)
+    return probs @ sd["fc.weight"].astype(np.float64).T + sd["fc.bias"].astype(np.float64)

@@ -244,6 +244,19 @@ def g8():
         for k, v in m.state_dict().items():
             out[f"{name}/{k}"] = v.numpy()
         out[f"{name}/x"], out[f"{name}/y"] = x.numpy(), y.numpy()
+    # CCCNN (model.py:443-538), non-grouped: shared conv stack per channel + autocorrelation head
+    for name, kw in (("cccnn_a", dict(input_size=64, output_size=2, channels=3, layer_sizes=[4, 6],
+                                      kernel_sizes=[3, 5], padding=1)),
+                     ("cccnn_b", dict(input_size=96, output_size=3, channels=4, layer_sizes=[5],
+                                      kernel_sizes=7, padding=3, activation=torch.nn.ReLU))):
+        m = ref.model.CCCNN(**kw)
+        m.eval()
+        x = torch.randn(4, kw["channels"], kw["input_size"])
+        with torch.no_grad():
+            y = m(x)
+        for k, v in m.state_dict().items():
+            out[f"{name}/{k}"] = v.numpy()
+        out[f"{name}/x"], out[f"{name}/y"] = x.numpy(), y.numpy()
     save("g8_models", **out)
 
 
