@@ -148,6 +148,16 @@ int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int
                        int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info,
                        void* stream);
 
+/* The same call in two halves, so that a caller can overlap other work with the long, sparsely
+ * occupied tail: _begin only ENQUEUES the head (input transpose + the IIR candidate launch, the
+ * part that is heavy on the memory system) and returns; _finish does everything else and
+ * synchronises.  Both take the arguments of ofp_detect_offline. */
+int ofp_detect_offline_begin(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                             int64_t warm, void* d_ws, int64_t ws_bytes, void* stream);
+int ofp_detect_offline_finish(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                              int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
+                              int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream);
+
 /* Streaming form: AmplitudeOnsetDetector.__call__ (detection.py:727-798) on
  * n_blocks consecutive blocks with the detector state carried in d_state
  * (ofp_stream_state_bytes() bytes, initialised by ofp_stream_state_init).

@@ -78,6 +78,9 @@ SIGNATURES = {
     "ofp_detect_workspace_bytes": (_i64, [_vp, _i64, _i64, _i64]),
     "ofp_detect_offline": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
                                           ctypes.POINTER(_i64), _vp]),
+    "ofp_detect_offline_begin": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "ofp_detect_offline_finish": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
+                                                 ctypes.POINTER(_i64), _vp]),
     "ofp_stream_state_bytes": (_i64, [_vp]),
     "ofp_stream_state_init": (ctypes.c_int, [_vp, _vp, _vp]),
     "ofp_stream_process": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),

@@ -126,7 +126,19 @@ class BatchDetector:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None):
+    def begin(self, x, warm=None):
+        """Enqueue only the head of `detect` (input transpose + the IIR candidate launch) on the
+        current stream and return; follow with ``detect(..., begun=True)`` and the same x/warm."""
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n_clips, N, C = x.shape
+        warm = int(0.5 * self.sr) if warm is None else int(warm)
+        ws = self.reserve(n_clips, N, warm)
+        check(self.d.lib.ofp_detect_offline_begin(self.d.handle, x.data_ptr(), n_clips, N, warm, ws.data_ptr(),
+                                                  ws.numel(), _stream_ptr(x.device)), "ofp_detect_offline_begin")
+
+    def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
         """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of
         device tensors: ``records`` (uint8 view of ofp_onset [n_clips, cap]),
         ``counts`` int64 [n_clips], ``rel`` float32 [n_clips, N', C] or None."""
@@ -148,10 +160,16 @@ class BatchDetector:
             }
         info = (ctypes.c_int64 * 16)()
         rel = out["rel"]
-        check(self.d.lib.ofp_detect_offline(
-            self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
-            out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
-            _stream_ptr(x.device)), "ofp_detect_offline")
+        if begun:  # the head was enqueued by begin(): run the remaining stages
+            check(self.d.lib.ofp_detect_offline_finish(
+                self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
+                out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
+                _stream_ptr(x.device)), "ofp_detect_offline_finish")
+        else:
+            check(self.d.lib.ofp_detect_offline(
+                self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
+                out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
+                _stream_ptr(x.device)), "ofp_detect_offline")
         self.last_info = dict(
             hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3],
             # stage durations, HIP events on the launch stream (milliseconds)

@@ -81,8 +81,14 @@ class FingerprintPipeline:
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
             self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self._head = torch.cuda.Event()
         side = self._side
-        side.wait_stream(main)
+        # head of the detector: transpose + the IIR candidate launch (heavy on the memory system)
+        self.detector.begin(x)
+        self._head.record(main)
+        # the spectral branch starts when the head is done and then shares the chip with the
+        # detector's long, sparsely occupied tail (verification rounds, followers, tracker)
+        side.wait_event(self._head)
         with torch.cuda.stream(side):
             self._ev[0].record(side)
             power = stft_power_dense(x, self.n_fft, self.hop, out=b["power"])
@@ -91,7 +97,7 @@ class FingerprintPipeline:
             self._ev[2].record(side)
             logits = self.classifier(mel.reshape(-1, self.n_mels))
             self._ev[3].record(side)
-        det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1])
+        det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1], begun=True)
         main.wait_stream(side)
         out = dict(records=det["records"], counts=det["counts"], cap=det["cap"], rel=det["rel"], power=power,
                    mel=mel, logits=logits.reshape(n_clips, C, -1, logits.shape[-1]),
