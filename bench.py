@@ -40,7 +40,7 @@ BYTES_MLP = 4 * NMELS + 4 * 8
 # WRITE_SIZE, /opt/skills/guides/MI355X_MICROARCH.md section HBM); filled from profiles/, else null
 TRAFFIC_BYTES_PER_LAUNCH = {}
 try:  # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), see profiles/README.md
-    _t = json.load(open(REPO / "profiles" / "r01" / "v4_pmc_traffic_per_kernel.json"))
+    _t = json.load(open(REPO / "profiles" / "r01" / "v5_pmc_traffic_per_kernel.json"))
     TRAFFIC_BYTES_PER_LAUNCH = {"hp": _t["k_hp_candidates"]["hbm_mb_per_launch"] * 1e6,
                                 "stft": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
 except Exception:
@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="audio seconds given to the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -181,7 +181,7 @@ def main():
             gl = logits.reshape(C, -1, 8)[:, :Hs].cpu().numpy()
             log_err = float(np.abs(gl - cb["logits"]).max() / np.abs(cb["logits"]).max())
             result["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s", "cores": 1, "kind": "port",
-                                      "sample": f"first {min(args.cpu_seconds, SECONDS):.0f} s of the same clip "
+                                      "sample": f"the first {min(args.cpu_seconds, SECONDS):.0f} s of the same 60 s clip "
                                                 f"({cb['frames']} frames) through oracle/ (C detector + numpy "
                                                 f"rFFT/mel/FCNN), {cb['seconds']:.2f} s wall"}
             result["parity"] = {"onset_indices_exact": bool(ok_idx), "rel_bit_exact": bool(ok_rel),
