@@ -237,6 +237,64 @@ int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float*
  * full auto-correlation of every map, summed over the K maps, soft-maxed over the lags. */
 int ofp_autocorr_softmax(const float* d_x, int64_t n, int32_t K, int32_t V, float* d_out, void* stream);
 
+/* ---- onset groups and their windows --------------------------------
+ * find_onset_groups (detection.py:131-189) per clip, straight from the records
+ * ofp_detect_offline wrote, without a host round trip.
+ *   d_records [n_clips][cap_per_clip], d_counts [n_clips]   as ofp_detect_offline leaves them
+ *   n_channels      row width (the reference uses max(channels)+1, detection.py:158,170);
+ *                   every record's channel must be in [0, n_channels)
+ *   max_distance, min_channels   detection.py:134-135
+ *   close_channel   detection.py:136,185; < 0 for None
+ *   d_groups  [n_clips][cap_groups][n_channels] int64 rows, -1 where a channel has no onset,
+ *             in the reference's order; d_n_groups [n_clips] kept groups per clip (may exceed
+ *             cap_groups: only cap_groups rows are stored)
+ *   d_ws      ofp_group_workspace_bytes(n_clips, cap_per_clip) bytes */
+int64_t ofp_group_workspace_bytes(int64_t n_clips, int64_t cap_per_clip);
+int ofp_group_onsets(const ofp_onset* d_records, int64_t cap_per_clip, const int64_t* d_counts, int64_t n_clips,
+                     int32_t n_channels, int64_t max_distance, int32_t min_channels, int32_t close_channel,
+                     int64_t* d_groups, int64_t cap_groups, int64_t* d_n_groups, void* d_ws, int64_t ws_bytes,
+                     void* stream);
+/* FrameExtractor.__call__ (data.py:90-120, max_shift = 0) over those rows: window c of a
+ * group starts at min_c(row) - pre_samples (use_min_onset != 0) or row[c] - pre_samples.
+ *   d_x [n_clips][n_samples][n_channels] interleaved
+ *   d_offsets [n_clips + 1] (out): first output row of each clip; [n_clips] = total rows
+ *   d_out [cap_total][n_channels][width]: rows of all clips back to back (rows beyond
+ *   cap_total are dropped).  Samples outside the clip read as 0. */
+int ofp_group_windows(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels,
+                      const int64_t* d_groups, int64_t cap_groups, const int64_t* d_n_groups, int32_t pre_samples,
+                      int32_t use_min_onset, int32_t width, float* d_out, int64_t cap_total, int64_t* d_offsets,
+                      void* stream);
+
+/* ---- cross-correlation lag and onset fixing --------------------------
+ * cross_correlation_lag (detection.py:195-268) for a batch of pairs.
+ *   d_x, d_y [n_pairs][n_in] float32; d: difference order applied first (np.diff, :238-239);
+ *   take_abs (:240-242); cutoff = normalization_cutoff (:247-250).  With n = n_in - d,
+ *   d_lo/d_hi [n_pairs] give the slice [lo, hi) of the normalised full correlation (length
+ *   2n-1) that is searched, i.e. what Python's slicing at :257 / :263 selects.
+ *   d_argmax [n_pairs]: np.argmax over the slice (first maximum), -1 for an empty slice; the
+ *   lag is max_adjust - argmax (:268).  d_cc (optional) [n_pairs][cc_stride]: the slice values.
+ * Dot products are accumulated in fp64 and rounded once to fp32 (see csrc/ofp_xcorr.hip).
+ * n_in <= 4096, d <= 4. */
+int ofp_xcorr_lag(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n_in, int32_t d, int32_t take_abs,
+                  int32_t cutoff, const int32_t* d_lo, const int32_t* d_hi, int32_t* d_argmax, float* d_cc,
+                  int32_t cc_stride, void* stream);
+/* fix_onsets (detection.py:373-451) for every onset group, one workgroup per group:
+ * median filter (scipy.ndimage 'reflect') over audio[a-look : b+look], d-th difference,
+ * rectification by direction (0 none, 1 "up", 2 "down"), abs, then for every channel after the
+ * earliest one cross_correlation_lag + adjust_onset (:299-352), in the reference's order.
+ *   d_audio [n_clips][n_samples][n_channels]; d_onsets [n_clips][cap_groups][n_channels] int64
+ *   (the layout ofp_group_onsets writes), updated in place (shift is added first, :414);
+ *   d_n_groups [n_clips] rows in use per clip (clamped to cap_groups) or NULL for all rows;
+ *   max_section: longest b - a + 2*(cutoff + tol) the work space holds (<= 4096);
+ *   d_status [n_clips][cap_groups]: 0 fixed, 1 = group outside the clip, with a missing
+ *   channel (-1) or longer than max_section (only shifted), 2 = row not in use.
+ *   d_ws: ofp_fix_onsets_workspace_bytes(n_clips * cap_groups, ...) bytes. */
+int64_t ofp_fix_onsets_workspace_bytes(int64_t n_groups, int32_t n_channels, int32_t max_section);
+int ofp_fix_onsets(const float* d_audio, int64_t n_clips, int64_t n_samples, int32_t n_channels, int64_t* d_onsets,
+                   int64_t cap_groups, const int64_t* d_n_groups, int32_t filter_size, int32_t d, int32_t direction, int32_t take_abs, int32_t zero_left,
+                   int32_t cutoff, int32_t tol, int32_t shift, int32_t max_section, int32_t* d_status, void* d_ws,
+                   int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

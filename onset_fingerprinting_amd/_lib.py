@@ -93,6 +93,15 @@ SIGNATURES = {
     "ofp_dense": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ofp_group_workspace_bytes": (_i64, [_i64, _i64]),
+    "ofp_group_onsets": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _i64,
+                                        _vp]),
+    "ofp_group_windows": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp,
+                                         _vp]),
+    "ofp_xcorr_lag": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ofp_fix_onsets_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "ofp_fix_onsets": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                      _i32, _i32, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

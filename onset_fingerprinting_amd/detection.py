@@ -10,6 +10,7 @@ Additional, batched entry points (`BatchDetector`, `detect_batch`) keep audio,
 relative envelope and onset records resident in HBM.
 """
 import ctypes
+from typing import Optional
 
 import numpy as np
 import torch
@@ -204,6 +205,168 @@ def detect_batch(x, block_size=128, sr=96000, device=0, warm=None, want_rel=True
     recs = BatchDetector.records_to_numpy(out)
     rel = out["rel"].cpu().numpy() if want_rel else None
     return recs, rel, bd.last_info
+
+
+def group_onsets_device(out, n_channels, max_distance=1000, min_channels=3, close_channel=None, cap_groups=None):
+    """find_onset_groups (detection.py:131-189) for every clip of a `BatchDetector.detect`
+    result, on the device.  Returns ``groups`` int64 [n_clips, cap_groups, n_channels] and
+    ``n_groups`` int64 [n_clips] (device tensors; no host synchronisation)."""
+    L = _lib.lib()
+    recs, counts = out["records"], out["counts"]
+    n_clips, cap = recs.shape[0], recs.shape[1]
+    cap_groups = int(cap_groups) if cap_groups is not None else cap
+    ws = torch.empty(int(L.ofp_group_workspace_bytes(n_clips, cap)), dtype=torch.uint8, device=recs.device)
+    groups = torch.empty((n_clips, cap_groups, n_channels), dtype=torch.int64, device=recs.device)
+    n_groups = torch.zeros(n_clips, dtype=torch.int64, device=recs.device)
+    check(L.ofp_group_onsets(recs.data_ptr(), cap, counts.data_ptr(), n_clips, n_channels, int(max_distance),
+                             int(min_channels), -1 if close_channel is None else int(close_channel),
+                             groups.data_ptr(), cap_groups, n_groups.data_ptr(), ws.data_ptr(), ws.numel(),
+                             _stream_ptr(recs.device)), "ofp_group_onsets")
+    return groups, n_groups
+
+
+def group_windows_device(x, groups, n_groups, frame_length, pre_samples, use_min_onset=True, cap_total=None):
+    """FrameExtractor (data.py:90-120, max_shift 0) over device group rows: x float32 CUDA
+    [n_clips, N, C] -> ``windows`` [cap_total, C, frame_length] (rows of all clips back to back)
+    and ``offsets`` int64 [n_clips + 1] (first row of each clip; last entry = rows in use)."""
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    n_clips, N, C = x.shape
+    cap_groups = groups.shape[1]
+    assert groups.shape == (n_clips, cap_groups, C) and groups.dtype == torch.int64 and groups.is_contiguous()
+    cap_total = int(cap_total) if cap_total is not None else n_clips * cap_groups
+    windows = torch.empty((cap_total, C, frame_length), dtype=torch.float32, device=x.device)
+    offsets = torch.empty(n_clips + 1, dtype=torch.int64, device=x.device)
+    check(_lib.lib().ofp_group_windows(x.data_ptr(), n_clips, N, C, groups.data_ptr(), cap_groups, n_groups.data_ptr(),
+                                  int(pre_samples), int(bool(use_min_onset)), int(frame_length), windows.data_ptr(),
+                                  cap_total, offsets.data_ptr(), _stream_ptr(x.device)), "ofp_group_windows")
+    return windows, offsets
+
+
+def find_onset_groups(onsets, channels, max_distance: int = 1000, min_channels: int = 3,
+                      close_channel: Optional[int] = None, device=0):
+    """detection.py:131-189: same arguments, same return (int array [G, max(channels)+1] or
+    None).  The lists go to the GPU as one clip's onset records and are grouped by
+    ``ofp_group_onsets``; channels must be non-negative."""
+    ch = np.asarray(channels, dtype=np.int64)
+    on = np.asarray(onsets, dtype=np.int64)
+    n = min(len(ch), len(on))  # zip() semantics, detection.py:160
+    width = int(max(channels)) + 1  # raises ValueError on an empty list as the reference does (:158)
+    if n and ch[:n].min() < 0:
+        raise ValueError("find_onset_groups: negative channel index")
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    rec = np.zeros(max(n, 1), dtype=ONSET_DTYPE)
+    rec["channel"][:n], rec["sample"][:n] = ch[:n], on[:n]
+    out = {"records": torch.from_numpy(rec.view(np.uint8).reshape(1, -1, 16)).to(dev),
+           "counts": torch.tensor([n], dtype=torch.int64, device=dev)}
+    groups, n_groups = group_onsets_device(out, width, max_distance, min_channels, close_channel)
+    g = int(n_groups.cpu()[0])
+    return groups[0, :g].cpu().numpy().astype(int) if g else None
+
+
+def _py_slice(start, stop, length):
+    s, e, _ = slice(start, stop).indices(length)
+    return s, max(e, s)
+
+
+def xcorr_lags_device(x, y, lo, hi, d=0, take_abs=False, normalization_cutoff=10, want_cc=False):
+    """Batched core of cross_correlation_lag: x, y float32 CUDA [P, n_in]; lo, hi int32 CUDA [P]
+    (slice of the normalised full correlation of the d-times differenced rows).  Returns argmax
+    int32 [P] (-1: empty slice) and, with want_cc, the slice values [P, max(hi-lo)]."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and y.shape == x.shape and y.is_contiguous()
+    P, n_in = x.shape
+    am = torch.empty(P, dtype=torch.int32, device=x.device)
+    cc = None
+    if want_cc:
+        width = max(int((hi - lo).max().item()), 1) if P else 1
+        cc = torch.zeros((P, width), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ofp_xcorr_lag(x.data_ptr(), y.data_ptr(), P, n_in, int(d), int(bool(take_abs)),
+                                   int(normalization_cutoff), lo.data_ptr(), hi.data_ptr(), am.data_ptr(),
+                                   cc.data_ptr() if cc is not None else None, cc.shape[1] if cc is not None else 0,
+                                   _stream_ptr(x.device)), "ofp_xcorr_lag")
+    return (am, cc) if want_cc else am
+
+
+def cross_correlation_lag(x: np.ndarray, y: np.ndarray, onsets=None, legal_lags=None, d: int = 0,
+                          normalization_cutoff: int = 10, onset_tolerance: int = 50, take_abs: bool = False,
+                          device=0):
+    """detection.py:195-268: same arguments and return (int lag, or None for an empty window)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    n = len(x) - d
+    if legal_lags is not None:  # detection.py:256-258
+        lo, hi = _py_slice(n - legal_lags[1], n - legal_lags[0], 2 * n - 1)
+        max_adjust = legal_lags[1]
+    elif onsets is not None:  # detection.py:259-264
+        current_lag = onsets[1] - onsets[0]
+        lo, hi = _py_slice(n - current_lag - onset_tolerance, n - current_lag + onset_tolerance, 2 * n - 1)
+        max_adjust = current_lag + onset_tolerance
+    else:
+        raise ValueError("cross_correlation_lag: give onsets or legal_lags")
+    if hi <= lo:
+        return None
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    am = xcorr_lags_device(torch.from_numpy(x[None]).to(dev), torch.from_numpy(y[None]).to(dev),
+                           torch.tensor([lo], dtype=torch.int32, device=dev),
+                           torch.tensor([hi], dtype=torch.int32, device=dev), d, take_abs, normalization_cutoff)
+    return -(int(am.cpu()[0]) - int(max_adjust))
+
+
+_DIRECTIONS = {None: 0, "up": 1, "down": 2}
+
+
+def fix_onsets_device(audio, onsets, filter_size=5, d=0, onset_direction=None, take_abs=False, zero_left=False,
+                      normalization_cutoff=10, onset_tolerance=30, shift_onsets=0, max_section=None, n_groups=None):
+    """fix_onsets on device tensors: audio float32 CUDA [N, C] with onsets int64 CUDA [G, C], or a
+    batch [n_clips, N, C] with [n_clips, cap_groups, C] (the layout `group_onsets_device` writes)
+    and `n_groups` int64 [n_clips].  Onsets are updated IN PLACE.  Returns status int32, one per
+    row: 0 fixed, 1 shifted only (group outside the clip, with a missing channel, or longer than
+    `max_section` samples, default 4096), 2 row not in use."""
+    assert audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous()
+    assert onsets.is_cuda and onsets.dtype == torch.int64 and onsets.is_contiguous()
+    if onset_direction not in _DIRECTIONS:
+        raise RuntimeError(f"Unknown onset direction {onset_direction=}!")
+    L = _lib.lib()
+    if audio.dim() == 2:
+        audio, onsets_b = audio.unsqueeze(0), onsets.unsqueeze(0)
+    else:
+        onsets_b = onsets
+    n_clips, N, C = audio.shape
+    G = onsets_b.shape[1]
+    assert onsets_b.shape == (n_clips, G, C)
+    max_section = 4096 if max_section is None else int(max_section)
+    status = torch.zeros(onsets.shape[:-1], dtype=torch.int32, device=audio.device)
+    ws = torch.empty(max(int(L.ofp_fix_onsets_workspace_bytes(n_clips * G, C, max_section)), 16), dtype=torch.uint8,
+                     device=audio.device)
+    check(L.ofp_fix_onsets(audio.data_ptr(), n_clips, N, C, onsets.data_ptr(), G,
+                           n_groups.data_ptr() if n_groups is not None else None, int(filter_size), int(d),
+                           _DIRECTIONS[onset_direction], int(bool(take_abs)), int(bool(zero_left)),
+                           int(normalization_cutoff), int(onset_tolerance), int(shift_onsets), max_section,
+                           status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(audio.device)),
+          "ofp_fix_onsets")
+    return status
+
+
+def fix_onsets(audio: np.ndarray, onsets: np.ndarray, filter_size: int = 5, d: int = 0, onset_direction=None,
+               take_abs: bool = False, zero_left: bool = False, normalization_cutoff: int = 10,
+               onset_tolerance: int = 30, shift_onsets: int = 0, device=0):
+    """detection.py:373-451: same arguments, returns the fixed copy of `onsets` [O, C].  A group
+    whose section would leave the clip (the reference's slice would wrap or shrink there) raises."""
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    a = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).to(dev)
+    o = torch.from_numpy(np.ascontiguousarray(onsets, dtype=np.int64).copy()).to(dev)
+    spread = int((np.max(onsets, axis=1) - np.min(onsets, axis=1)).max(initial=0))
+    status = fix_onsets_device(a, o, filter_size, d, onset_direction, take_abs, zero_left, normalization_cutoff,
+                               onset_tolerance, shift_onsets,
+                               max_section=max(spread + 2 * (normalization_cutoff + onset_tolerance), 1))
+    if int(status.max().item() if status.numel() else 0) != 0:
+        raise IndexError("fix_onsets: an onset group lies within normalization_cutoff + onset_tolerance samples of "
+                         "the clip edge (or spans more than 4096 samples)")
+    return o.cpu().numpy().astype(np.asarray(onsets).dtype, copy=False)
 
 
 def detect_onsets(x: np.ndarray, sr: int = 96000, method="amp"):

@@ -70,6 +70,26 @@ def c4_clip(clip, seconds=10.0, n_channels=4, sr=SR, seed=3):
     return drum_hits(n_channels, seconds, sr, seed + clip, poisson_rate=4.0, gain=gain)
 
 
+def sensor_hits(seed, n_channels=4, n=24000, hits=12, jitter=12):
+    """Calibration-hit style input for fix_onsets (detection.py:373-451): every hit reaches the
+    channels with a lag below 60 samples; returns (audio [n, C] float32, onsets [hits, C] int64)
+    where the onsets are the true arrival times disturbed by +-`jitter` samples."""
+    rng = np.random.default_rng(seed)
+    audio = (0.01 * rng.standard_normal((n, n_channels))).astype(np.float32)
+    t = np.arange(300)
+    onsets = []
+    for h in range(hits):
+        t0 = 1500 + h * ((n - 3000) // hits) + int(rng.integers(0, 200))
+        row = []
+        for c in range(n_channels):
+            lag = int(rng.integers(0, 60))
+            s = np.exp(-t / 60.0) * np.sin(2 * np.pi * t / 23.0) * (0.5 + 0.5 * rng.random())
+            audio[t0 + lag:t0 + lag + 300, c] += s.astype(np.float32)
+            row.append(t0 + lag + int(rng.integers(-jitter, jitter + 1)))
+        onsets.append(row)
+    return audio, np.asarray(onsets, np.int64)
+
+
 def n_frames(n_samples, n_fft, hop):
     """frames per channel of the dense metric: 1 + (N - F)//B (SURVEY.md 8a a9)."""
     return 0 if n_samples < n_fft else 1 + (n_samples - n_fft) // hop

@@ -371,3 +371,23 @@ void oracle_detector_get_state(const oracle_detector* d, float* zi, float* yf, f
     if (prev) memcpy(prev, d->prev, C * sizeof(double));
     if (deb) memcpy(deb, d->deb, C * sizeof(long));
 }
+
+/* ---- cross-correlation ------------------------------------------------
+ * cross_correlation_lag, reference detection.py:244-250: entries [lo, hi) of
+ *   cc = np.correlate(x, y, "full");  cc[:n] /= normalizer;  cc[n:] /= normalizer[n-2::-1]
+ * with normalizer[i] = max(i + 1, cutoff) for i < cutoff, i + 1 beyond (detection.py:247-248).
+ * Canon shared with the HIP kernel: every dot product is accumulated in fp64 over ascending i
+ * (fp32 x fp32 products are exact in fp64), rounded once to fp32 -- the dtype np.correlate
+ * returns for float32 input -- and divided in fp32 (numpy divides the float32 value by the int64
+ * count in fp64 and rounds to fp32, which is the correctly rounded fp32 quotient). */
+void oracle_xcorr_slice(const float* x, const float* y, long n, long cutoff, long lo, long hi, float* cc) {
+    for (long j = lo; j < hi; ++j) {
+        long k = j - (n - 1); /* cc[j] = sum_i x[i + k] * y[i] */
+        long i0 = k < 0 ? -k : 0, i1 = k > 0 ? n - k : n;
+        double acc = 0.0;
+        for (long i = i0; i < i1; ++i) acc += (double)x[i + k] * (double)y[i];
+        long m = j < n ? j : 2 * n - 2 - j; /* index into the normalizer */
+        long cnt = m < cutoff ? cutoff : m + 1;
+        cc[j - lo] = (float)acc / (float)cnt;
+    }
+}
