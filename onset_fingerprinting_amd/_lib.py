@@ -52,6 +52,7 @@ class DetectTuning(ctypes.Structure):
         ("ar_coarse_warm", ctypes.c_int64),
         ("hp_candidates", ctypes.c_int64),
         ("hp_candidate_offset", ctypes.c_int64),
+        ("ar_guess", ctypes.c_int64),
     ]
 
 

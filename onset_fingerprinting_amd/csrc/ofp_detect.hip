@@ -308,6 +308,82 @@ __global__ __launch_bounds__(64) void k_ar_coarse(ArArgs a, int64_t n_threads, u
     used[sidx + 1] = ofp_f2u(cs.ys);
 }
 
+// Guess for a SYMMETRIC slow follower (attack == release, the reference's default 2205/2205):
+// the recurrence is then a plain exponential average apart from its roundings, so its state at
+// a chunk boundary b is  S_b = q^L S_{b-1} + P_{b-1},  P_j = sum_i c q^(L-1-i) x[jL+i],  q = 1-c,
+// S_0 = floor.  k_ar_sym_local evaluates every P_j with one wave (fp64), k_ar_sym_combine chains
+// them per channel: microseconds instead of a sequential pass over Wc samples per chunk.  The
+// exact warm-up of chunk k starts at boundary k - W/L (make_layout makes W a multiple of L); the
+// fast follower starts from the floor, and the warm-up is long enough to forget that.
+// Only a guess: the chunk passes verify every state bit for bit.
+__global__ __launch_bounds__(64) void k_ar_sym_local(ArArgs a, int64_t n_waves, double* __restrict__ P) {
+    const int64_t id = blockIdx.x;  // one wave per (chain, chunk)
+    if (id >= n_waves) return;
+    const int lane = threadIdx.x;
+    const int64_t j = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t base = j * a.L;
+    const int64_t len = min(a.L, a.g.U - base);
+    const float* xs = a.xdb + chain * a.g.U + base;
+    const double c = (double)a.sa, q = 1.0 - c;
+    double q64 = 1.0, w = c;  // q^64 and this lane's first weight c q^lane
+    for (int i = 0; i < 64; ++i) {
+        q64 *= q;
+        if (i < lane) w *= q;
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    const double q128 = q64 * q64;
+    double w1 = w * q64;
+    int64_t t = lane;
+    for (; t + 64 < len; t += 128) {  // sample len-1-t carries weight c q^t
+        acc0 += w * (double)xs[len - 1 - t];
+        acc1 += w1 * (double)xs[len - 1 - t - 64];
+        w *= q128;
+        w1 *= q128;
+    }
+    if (t < len) acc0 += w * (double)xs[len - 1 - t];
+    double acc = acc0 + acc1;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) P[id] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_ar_sym_combine(ArArgs a, const double* __restrict__ P,
+                                                       uint32_t* __restrict__ used) {
+    __shared__ double sp[1024];
+    __shared__ float ss[1024];
+    const int64_t chain = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t shift = a.W / a.L;  // boundaries between a chunk and the start of its warm-up
+    const double qL = exp((double)a.L * log(1.0 - (double)a.sa));
+    double S = (double)a.floor_db;  // state at boundary b0
+    for (int64_t b0 = 0; b0 < a.n_chunks; b0 += 1024) {
+        const int nb = (int)min<int64_t>(1024, a.n_chunks - b0);
+        __syncthreads();
+        for (int i = lane; i < nb; i += 64) sp[i] = P[chain * a.n_chunks + b0 + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < nb; ++i) {
+                ss[i] = (float)S;  // state at boundary b0 + i
+                S = qL * S + sp[i];
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < nb; i += 64) {
+            const int64_t k = b0 + i + shift;  // the chunk whose warm-up starts at this boundary
+            if (k < a.n_chunks) {
+                const int64_t sidx = (chain * a.n_chunks + k) * 2;
+                used[sidx] = ofp_f2u(a.floor_db);
+                used[sidx + 1] = ofp_f2u(b0 + i > 0 ? ss[i] : a.floor_db);
+            }
+        }
+    }
+    for (int64_t k = lane; k < min(shift, a.n_chunks); k += 64) {  // warm-up starts at sample 0: true state
+        const int64_t sidx = (chain * a.n_chunks + k) * 2;
+        used[sidx] = ofp_f2u(a.floor_db);
+        used[sidx + 1] = ofp_f2u(a.floor_db);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_ar_warm(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
@@ -530,7 +606,9 @@ struct HpCand {
     int8_t* sel;      // [clips][chunks][C] chosen slot, -1 unknown
     uint8_t* done;    // [clips][chunks][C] output written
     uint8_t* nxt;     // [clips][chunks][C][R+1] slot of chunk k matching E[k-1][r], 255 none
-    int* counters;    // [0] chains with an unresolved chunk after the last resolve
+    uint8_t* guessed; // [clips][chunks][C] sel[] is an unverified plurality guess (see k_hp_resolve)
+    int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
+                      // unverified guesses
     int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
     __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
         return ((((clip * st.n_chunks + k) * st.g.C + c) * (R + 1)) + r) * 4;
@@ -538,8 +616,19 @@ struct HpCand {
 };
 
 
-// pass A: thread = (clip, channel, candidate, chunk), chunk fastest
-__global__ __launch_bounds__(64) void k_hp_candidates(HpCand a, int64_t n_threads) {
+// pass A: thread = (clip, channel, chunk, candidate), candidate fastest.
+// SPREAD: the launch has no more workgroups than the chip has CUs (C2: 704 waves for 1024 SIMDs).
+// Each wave is a long dependent chain, so two waves sharing a SIMD while other SIMDs idle cost
+// ~30 % (measured: the same launch took 2.3 or 3.1 ms depending on where the dispatcher happened
+// to put the waves).  A 4-wave workgroup that claims more than half of the CU's LDS is alone on
+// its CU, one wave per SIMD -- placement becomes deterministic.
+constexpr int HP_CAND_THREADS = 256;
+template <bool SPREAD>
+__global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int64_t n_threads) {
+    if (SPREAD) {
+        __shared__ char claim[96 * 1024];
+        if (n_threads < 0) claim[threadIdx.x] = 1;  // never taken: keeps the allocation alive
+    }
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
@@ -560,6 +649,7 @@ __global__ __launch_bounds__(64) void k_hp_candidates(HpCand a, int64_t n_thread
     if (r == 0) {
         a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
         a.done[(clip * st.n_chunks + k) * C + c] = 0;
+        a.guessed[(clip * st.n_chunks + k) * C + c] = 0;
         a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
     }
     HpStep s;
@@ -601,15 +691,78 @@ __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
     a.nxt[id] = res;
 }
 
-// pass B2: one wave per chain walks the match table (staged through LDS in tiles)
+// The slot of chunk k whose END state is shared by the most candidates (at least two), -1 if
+// all end states differ.  Candidates that agree with each other have merged, and then almost
+// surely with the true trajectory as well: a guess that k_hp_resolve verifies afterwards.
+// Whole wave: lane r < R holds candidate r.
+__device__ int hp_plurality(const HpCand& a, int64_t clip, int64_t k, int c) {
+    const int lane = threadIdx.x & 63;
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    if (lane < a.R) {
+        const uint32_t* e = a.E + a.slot(clip, k, c, lane);
+        e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+    }
+    int cnt = 0;
+    for (int q = 0; q < a.R; ++q)
+        cnt += (__shfl(e0, q) == e0 && __shfl(e1, q) == e1 && __shfl(e2, q) == e2 && __shfl(e3, q) == e3) ? 1 : 0;
+    // most votes, lowest slot on ties; key = cnt * 64 + (63 - lane)
+    int key = (lane < a.R && cnt >= 2) ? cnt * 64 + (63 - lane) : -1;
+    for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+    return key < 0 ? -1 : 63 - (key & 63);
+}
+
+// pass B2: one wave per chain walks the match table (staged through LDS in tiles).
+//
+// A chunk k whose true start state E[k-1][sel] matches none of its candidates is a break: it has
+// to be run from that state before its end state is known, which costs a round.  Instead of
+// stopping there, the walk continues from the plurality end state of chunk k (hp_plurality) and
+// marks the chunk `guessed`; k_hp_run runs chunk k from its true start state in the same round
+// (slot R), and the NEXT resolve compares that exact end state with the guess.  Right (the usual
+// case): nothing else to do.  Wrong: slot R is selected and every later chunk of the chain is
+// invalidated and walked again.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     __shared__ uint8_t tile[64 * (HP_MAXR + 1)];
+    __shared__ int8_t stile[64];
     const int C = a.st.g.C, R1 = a.R + 1;
     const int64_t chain = blockIdx.x;  // clip*C + c
     const int c = (int)(chain % C);
     const int64_t clip = chain / C;
     const int64_t nk = a.st.n_chunks;
     const int lane = threadIdx.x;
+    // --- verify the guesses of earlier rounds whose chunk has been run since
+    int64_t wrong = nk;
+    bool pending = false;
+    for (int64_t k = lane; k < nk; k += 64) {
+        const int64_t ci = (clip * nk + k) * C + c;
+        if (!a.guessed[ci]) continue;
+        if (!a.done[ci]) {
+            pending = true;
+            continue;
+        }
+        const uint32_t* ex = a.E + a.slot(clip, k, c, a.R);
+        const uint32_t* eg = a.E + a.slot(clip, k, c, a.sel[ci]);
+        if (ex[0] == eg[0] && ex[1] == eg[1] && ex[2] == eg[2] && ex[3] == eg[3]) a.guessed[ci] = 0;
+        else wrong = min(wrong, k);
+    }
+    for (int o = 32; o > 0; o >>= 1) wrong = min(wrong, __shfl_xor(wrong, o));
+    pending = __any(pending);
+    if (wrong < nk) {  // first wrong guess: select the exact slot there, forget everything after it
+        for (int64_t k = wrong + lane; k < nk; k += 64) {
+            const int64_t ci = (clip * nk + k) * C + c;
+            a.guessed[ci] = 0;
+            if (k == wrong) {
+                a.sel[ci] = (int8_t)a.R;
+            } else {
+                a.sel[ci] = -1;
+                a.done[ci] = 0;
+            }
+        }
+        if (lane == 0) a.pos[chain] = (int32_t)(wrong + 1);
+        pending = false;  // guesses before `wrong` were verified or are still counted below
+        for (int64_t k = lane; k < wrong; k += 64) pending = pending || a.guessed[(clip * nk + k) * C + c];
+        pending = __any(pending);
+    }
+    __syncthreads();
     // resume where the previous round stopped: chunks before pos[] are resolved
     const int64_t kstart = max<int64_t>(1, a.pos[chain]);
     int cur = a.sel[(clip * nk + kstart - 1) * C + c];  // slot chosen for the previous chunk
@@ -622,25 +775,47 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             const int bk = i / R1, r = i % R1;
             tile[i] = a.nxt[(((clip * nk + k0 + bk) * C + c) * R1) + r];
         }
+        if (lane < nblk) stile[lane] = a.sel[(clip * nk + k0 + lane) * C + c];
         __syncthreads();
-        if (lane == 0) {
-            for (int bk = 0; bk < nblk; ++bk) {
-                int8_t* sp = a.sel + (clip * nk + k0 + bk) * C + c;
-                int s = *sp;
-                if (s < 0) {
-                    const uint8_t m = tile[bk * R1 + cur];
-                    if (m == 255) { stuck = true; reached = k0 + bk; break; }
-                    s = m;
-                    *sp = (int8_t)s;
+        int bk = 0;  // uniform: next chunk of the tile to visit
+        while (bk < nblk) {
+            int brk = -1;  // chunk of the tile where lane 0 met a break
+            if (lane == 0) {
+                for (; bk < nblk; ++bk) {
+                    int s = stile[bk];
+                    if (s < 0) {
+                        const uint8_t m = tile[bk * R1 + cur];
+                        if (m == 255) { brk = bk; break; }
+                        s = m;
+                        stile[bk] = (int8_t)s;
+                    }
+                    cur = s;
                 }
-                cur = s;
             }
+            brk = __shfl(brk, 0);
+            if (brk < 0) break;
+            // break: continue from the plurality end state, if there is one (whole wave)
+            const int gs = hp_plurality(a, clip, k0 + brk, c);
+            if (gs < 0) {
+                stuck = true;
+                reached = k0 + brk;
+                break;
+            }
+            if (lane == 0) {
+                stile[brk] = (int8_t)gs;
+                a.guessed[(clip * nk + k0 + brk) * C + c] = 1;
+                pending = true;
+                cur = gs;
+            }
+            bk = brk + 1;
         }
-        stuck = __shfl(stuck ? 1 : 0, 0) != 0;
+        __syncthreads();
+        if (lane < nblk) a.sel[(clip * nk + k0 + lane) * C + c] = stile[lane];
     }
     if (lane == 0) {
         a.pos[chain] = (int32_t)reached;
         if (stuck) atomicAdd(a.counters, 1);
+        if (pending) atomicAdd(a.counters + 1, 1);
     }
 }
 
@@ -675,10 +850,11 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t start = k * st.L;
     const int64_t end = min(start + st.L, st.g.V);
     hp_span<true>(st, s, chain, start, end);
-    if (a.sel[ci] < 0) {
+    if (a.sel[ci] < 0 || a.guessed[ci]) {
         // no candidate matched: this exact run becomes slot R.  sel[ci] itself is NOT written
         // here (a successor running in this same launch must not see a half-filled slot); the
-        // next k_hp_match finds slot R and k_hp_resolve selects it.
+        // next k_hp_match finds slot R and k_hp_resolve selects it (or, for a guessed chunk,
+        // compares it with the guess).
         uint32_t* u = a.U + a.slot(clip, k, c, a.R);
         uint32_t* e = a.E + a.slot(clip, k, c, a.R);
 #pragma unroll
@@ -992,10 +1168,11 @@ struct Layout {
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R;
     int64_t ar_L, ar_W, ar_Wc, ar_chunks;
+    bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_pos, o_ar_state, o_mm_state,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_guess, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
         o_thr_mn, o_thr_mx, o_first, o_last, o_flags, total;
 };
 
@@ -1025,6 +1202,21 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.ar_L = pick(d->t.ar_chunk, 4096);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
     l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
+    // symmetric slow follower: closed-form guess (k_ar_sym_local/combine) instead of the
+    // sequential approximate pass.  The guess is good to ~10 ulps (it ignores the fp32 roundings
+    // of the real trajectory) and a difference of a few ulps dies out like exp(-t/tau) only, so
+    // the exact warm-up stays 11 tau: shorter ones leave chunk starts an ulp off (2 % at 5.5 tau)
+    // and each repair pass costs more than the steps saved.  The fast follower starts from the
+    // floor and needs 24 of its own time constants.
+    const bool sym = p.slow_attack == p.slow_release && p.slow_attack > 0 && p.slow_attack < 1;
+    l.ar_sym = d->t.ar_guess == 2 ? sym : (d->t.ar_guess == 1 ? false : sym);
+    if (l.ar_sym) {
+        const float cf = std::min(p.fast_attack, p.fast_release);
+        const double tau_s = 1.0 / p.slow_attack, tau_f = cf > 0 ? 1.0 / cf : 1.0;
+        l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(std::max(11.0 * tau_s, 24.0 * tau_f), 4.0e6), 1024));
+        l.ar_W = align_up(l.ar_W, l.ar_L);  // the guess is available at chunk boundaries
+        l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(16.0 * tau_s, 8.0e6), 1024));
+    }
     l.mm_L = pick(d->t.mm_chunk, 8192);
     l.mm_W = pick_warm(d->t.mm_warm, 49152);
     l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
@@ -1047,9 +1239,11 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_sel = take(cc);
         l.o_hp_done = take(cc);
         l.o_hp_nxt = take(cc * (l.hp_R + 1));
+        l.o_hp_guess = take(cc);
         l.o_hp_pos = take(n_clips * g.C * 4);
     }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
+    l.o_ar_P = take(n_clips * l.ar_chunks * g.C * 8);
     l.o_mm_state = take(3 * n_clips * l.mm_chunks * g.C * 2 * 4);
     l.o_thr_mn = take(n_clips * l.nb * g.C * 4);
     l.o_thr_mx = take(n_clips * l.nb * g.C * 4);
@@ -1134,6 +1328,12 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
     for (int k = 0; k < 10 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
+    if (e == hipSuccess) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            d->n_cus = cus;
+    }
     if (e != hipSuccess) {
         ofp_detector_destroy(d);
         return ofp::fail(OFP_ERR_HIP, "ofp_detector_create: %s", hipGetErrorString(e));
@@ -1229,6 +1429,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.sel = reinterpret_cast<int8_t*>(ws + l.o_hp_sel);
         hc.done = reinterpret_cast<uint8_t*>(ws + l.o_hp_done);
         hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
+        hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         const int64_t nA = chains * l.hp_chunks * hc.R;
@@ -1236,23 +1437,28 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nC = chains * l.hp_chunks;
         if (phase != 2) {
             OFP_HIP(hipMemsetAsync(hc.pos, 0, chains * 4, stream));
-            hipLaunchKernelGGL(k_hp_candidates, dim3((unsigned)cdiv(nA, 64)), dim3(64), 0, stream, hc, nA);
+            const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
+            if ((int64_t)cand_grid <= d->n_cus)
+                hipLaunchKernelGGL(k_hp_candidates<true>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
+            else
+                hipLaunchKernelGGL(k_hp_candidates<false>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
             OFP_LAUNCH_CHECK("k_hp_candidates");
             OFP_HIP(hipEventRecord(ev[7], stream));
         }
         hp_cand_timed = true;
         if (phase == 1) return OFP_OK;
         for (int it = 0;; ++it) {
-            OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+            OFP_HIP(hipMemsetAsync(d_changed, 0, 2 * sizeof(int), stream));
             hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
             OFP_LAUNCH_CHECK("k_hp_match");
             hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
             OFP_LAUNCH_CHECK("k_hp_resolve");
-            int stuck = 0;
-            OFP_HIP(hipMemcpyAsync(&stuck, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+            int flags[2] = {0, 0};  // chains stuck at a break / chains with unverified guesses
+            OFP_HIP(hipMemcpyAsync(flags, d_changed, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
             hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
             OFP_LAUNCH_CHECK("k_hp_run");
             OFP_HIP(hipStreamSynchronize(stream));
+            const int stuck = flags[0] + flags[1];
             info[0] += 1;
             info[3] += stuck;
             if (stuck == 0) break;
@@ -1285,8 +1491,17 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nt = chains * l.ar_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
-        hipLaunchKernelGGL(k_ar_coarse, dim3(grid), dim3(64), 0, stream, a, nt, used);
-        OFP_LAUNCH_CHECK("k_ar_coarse");
+        if (l.ar_sym) {
+            double* P = reinterpret_cast<double*>(ws + l.o_ar_P);
+            hipLaunchKernelGGL(k_ar_sym_local, dim3((unsigned)nt), dim3(64), 0, stream, a, nt, P);
+            OFP_LAUNCH_CHECK("k_ar_sym_local");
+            hipLaunchKernelGGL(k_ar_sym_combine, dim3((unsigned)chains), dim3(64), 0, stream, a, (const double*)P,
+                               used);
+            OFP_LAUNCH_CHECK("k_ar_sym_combine");
+        } else {
+            hipLaunchKernelGGL(k_ar_coarse, dim3(grid), dim3(64), 0, stream, a, nt, used);
+            OFP_LAUNCH_CHECK("k_ar_coarse");
+        }
         hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_ar_warm");
         int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, d_changed, d->t.max_passes,

@@ -14,4 +14,5 @@ struct ofp_detector {
     double* d_on_d = nullptr;  // [C] the Python double, used for row 0 in manual mode
     ofp_detect_tuning t;
     hipEvent_t ev[10] = {};     // stage timing (ofp_detect_offline h_info)
+    int n_cus = 256;            // compute units of the device the detector was created on
 };
