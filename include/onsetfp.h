@@ -108,8 +108,10 @@ typedef struct ofp_detect_tuning {
     int32_t max_passes;          /* repair passes before giving up (0: no limit) */
     int64_t ar_coarse_warm;      /* follower stage: approximate-arithmetic warm-up that
                                     produces the guess for the exact warm-up (<0: none) */
-    int64_t hp_candidates;       /* IIR stage: speculative candidates per chunk (default 8, max 16) */
-    int64_t hp_candidate_offset; /* IIR stage: samples between candidate starts (default 1021) */
+    int64_t hp_candidates;       /* IIR stage: speculative candidates per chunk (default 16, max 16) */
+    int64_t hp_candidate_offset; /* IIR stage: samples between candidate starts (default 8); < 0: all
+                                    candidates of a chunk start at the same sample from slightly
+                                    different states */
     int64_t ar_guess;            /* follower stage, how the exact warm-up gets its starting guess:
                                     0 auto, 1 sequential approximate pass, 2 closed-form dot product
                                     (needs slow attack == slow release; auto picks it when they are) */

@@ -32,6 +32,7 @@
 //   scan + state machine: threshold crossings, hysteresis, cooldown (:764-797)
 //   backtrack (:800-825)
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -604,7 +605,11 @@ struct HpCand {
     uint32_t* U;      // [clips][chunks][C][R+1][4]
     uint32_t* E;      // same shape
     int8_t* sel;      // [clips][chunks][C] chosen slot, -1 unknown
-    uint8_t* done;    // [clips][chunks][C] output written
+    uint8_t* done;    // [clips][chunks][C][S] output of sub-chunk written
+    int S;            // sub-chunks per chunk: every candidate also records its state at the S-1
+                      // inner boundaries, so a chunk whose start matched a candidate is run by S
+                      // lanes at once (its candidate's trajectory is exact all the way through)
+    uint32_t* M;      // [clips][chunks][C][R][S-1][4] those states
     uint8_t* nxt;     // [clips][chunks][C][R+1] slot of chunk k matching E[k-1][r], 255 none
     uint8_t* guessed; // [clips][chunks][C] sel[] is an unverified plurality guess (see k_hp_resolve)
     int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
@@ -613,6 +618,9 @@ struct HpCand {
     __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
         return ((((clip * st.n_chunks + k) * st.g.C + c) * (R + 1)) + r) * 4;
     }
+    __device__ __host__ int64_t mslot(int64_t clip, int64_t k, int c, int r, int sb) const {
+        return (((((clip * st.n_chunks + k) * st.g.C + c) * R + r) * (S - 1)) + sb) * 4;
+    }
 };
 
 
@@ -620,13 +628,13 @@ struct HpCand {
 // SPREAD: the launch has no more workgroups than the chip has CUs (C2: 704 waves for 1024 SIMDs).
 // Each wave is a long dependent chain, so two waves sharing a SIMD while other SIMDs idle cost
 // ~30 % (measured: the same launch took 2.3 or 3.1 ms depending on where the dispatcher happened
-// to put the waves).  A 4-wave workgroup that claims more than half of the CU's LDS is alone on
+// to put the waves).  A 4-wave workgroup that claims 100 of the CU's 160 KiB of LDS is alone on
 // its CU, one wave per SIMD -- placement becomes deterministic.
 constexpr int HP_CAND_THREADS = 256;
 template <bool SPREAD>
 __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int64_t n_threads) {
     if (SPREAD) {
-        __shared__ char claim[96 * 1024];
+        __shared__ char claim[100 * 1024];
         if (n_threads < 0) claim[threadIdx.x] = 1;  // never taken: keeps the allocation alive
     }
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,20 +656,33 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
     const int64_t si = a.slot(clip, k, c, r);
     if (r == 0) {
         a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
-        a.done[(clip * st.n_chunks + k) * C + c] = 0;
+        for (int sb = 0; sb < a.S; ++sb) a.done[((clip * st.n_chunks + k) * C + c) * a.S + sb] = 0;
         a.guessed[(clip * st.n_chunks + k) * C + c] = 0;
         a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
     }
     HpStep s;
     s.coeffs(st.b, st.a);
     s.z[0] = s.z[1] = s.z[2] = s.z[3] = 0.0f;  // true state at 0 (detection.py:497), guess elsewhere
+    // The candidates of a chunk must reach the loud events of the window with DIFFERENT rounding
+    // histories (independent chances to coalesce with the true trajectory): staggered starts,
+    // delta samples apart (default 8).  delta == 0 (tuning < 0): all start at the same sample from
+    // slightly different states (r/1024 in z[0]; the difference decays below an ulp within ~200
+    // samples, the histories stay distinct).
+    if (a.delta == 0) s.z[0] = (float)r * 0.0009765625f;
     const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
     hp_span<false>(st, s, chain, ws, start);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.U[si + i] = ofp_f2u(s.z[i]);
-    hp_span<false>(st, s, chain, start, end);
+    const int64_t Ls = st.L / a.S;
+#pragma unroll 1
+    for (int sb = 0; sb < a.S; ++sb) {
+        const int64_t t0 = min(start + sb * Ls, end);
+        const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
+        hp_span<false>(st, s, chain, t0, t1);
+        uint32_t* dst = sb == a.S - 1 ? a.E + si : a.M + a.mslot(clip, k, c, r, sb);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a.E[si + i] = ofp_f2u(s.z[i]);
+        for (int i = 0; i < 4; ++i) dst[i] = ofp_f2u(s.z[i]);
+    }
 }
 
 // pass B1: nxt[k][c][r_prev] for every chunk k >= 1 (parallel)
@@ -735,7 +756,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     for (int64_t k = lane; k < nk; k += 64) {
         const int64_t ci = (clip * nk + k) * C + c;
         if (!a.guessed[ci]) continue;
-        if (!a.done[ci]) {
+        if (!a.done[ci * a.S]) {  // a guessed chunk is run whole by its sub-chunk 0 lane
             pending = true;
             continue;
         }
@@ -754,7 +775,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
                 a.sel[ci] = (int8_t)a.R;
             } else {
                 a.sel[ci] = -1;
-                a.done[ci] = 0;
+                for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
             }
         }
         if (lane == 0) a.pos[chain] = (int32_t)(wrong + 1);
@@ -821,26 +842,39 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
 
 // pass C: run every chunk whose true start state is known and that has not produced its
 // output yet, from that state; a chunk without a matching candidate fills slot R.
+// thread = (chain, chunk, sub-chunk).  A chunk whose start state matched candidate sel[] is run
+// by its S lanes in parallel, lane sb > 0 starting from that candidate's recorded inner state;
+// a chunk that starts from an unmatched state (a break, guessed or not) or whose own slot is the
+// exact re-run has no such states and is run whole by lane 0.
 __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
-    const int64_t k = id % st.n_chunks;
-    const int64_t chain = id / st.n_chunks;
+    const int sb = (int)(id % a.S);
+    const int64_t kc = id / a.S;
+    const int64_t k = kc % st.n_chunks;
+    const int64_t chain = kc / st.n_chunks;
     const int C = st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
     const int64_t ci = (clip * st.n_chunks + k) * C + c;
-    if (a.done[ci]) return;
+    if (a.done[ci * a.S + sb]) return;
     int sp = 0;
     if (k > 0) {
         sp = a.sel[ci - C];
         if (sp < 0) return;  // predecessor not resolved yet
     }
+    const int own = a.sel[ci];
+    const bool whole = own < 0 || own >= a.R || a.guessed[ci];  // no exact inner states
+    if (whole && sb > 0) return;
     HpStep s;
     s.coeffs(st.b, st.a);
     uint32_t xin[4] = {0u, 0u, 0u, 0u};
-    if (k > 0) {
+    if (sb > 0) {
+        const uint32_t* m = a.M + a.mslot(clip, k, c, own, sb - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xin[i] = m[i];
+    } else if (k > 0) {
         const uint32_t* e = a.E + a.slot(clip, k - 1, c, sp);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xin[i] = e[i];
@@ -849,8 +883,11 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     for (int i = 0; i < 4; ++i) s.z[i] = ofp_u2f(xin[i]);
     const int64_t start = k * st.L;
     const int64_t end = min(start + st.L, st.g.V);
-    hp_span<true>(st, s, chain, start, end);
-    if (a.sel[ci] < 0 || a.guessed[ci]) {
+    const int64_t Ls = st.L / a.S;
+    const int64_t t0 = whole ? start : min(start + sb * Ls, end);
+    const int64_t t1 = (whole || sb == a.S - 1) ? end : min(start + (sb + 1) * Ls, end);
+    hp_span<true>(st, s, chain, t0, t1);
+    if (own < 0 || a.guessed[ci]) {
         // no candidate matched: this exact run becomes slot R.  sel[ci] itself is NOT written
         // here (a successor running in this same launch must not see a half-filled slot); the
         // next k_hp_match finds slot R and k_hp_resolve selects it (or, for a guessed chunk,
@@ -863,7 +900,11 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
             e[i] = ofp_f2u(s.z[i]);
         }
     }
-    a.done[ci] = 1;
+    if (whole) {
+        for (int q = 0; q < a.S; ++q) a.done[ci * a.S + q] = 1;
+    } else {
+        a.done[ci * a.S + sb] = 1;
+    }
 }
 
 // ---- elementwise stages (planar, in place) -------------------------------------------
@@ -1166,13 +1207,13 @@ struct Layout {
     Geom g;
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
-    int hp_R;
+    int hp_R, hp_S;
     int64_t ar_L, ar_W, ar_Wc, ar_chunks;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_nxt, o_hp_guess, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
         o_thr_mn, o_thr_mx, o_first, o_last, o_flags, total;
 };
 
@@ -1198,7 +1239,11 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.hp_L = pick(d->t.hp_chunk, 8192);
     l.hp_W = pick_warm(d->t.hp_warm, 49152);
     l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, 16)));
-    l.hp_delta = pick(d->t.hp_candidate_offset, 1021);
+    // candidate starts 8 samples apart: distinct rounding histories (measured over nine inputs: as
+    // few verification rounds as with ~1000), yet the 16 lanes of a chunk read 4 cache lines per
+    // load instead of 16 and no lane runs much longer than W + L.  < 0: common start, see kernel.
+    l.hp_delta = d->t.hp_candidate_offset < 0 ? 0 : pick(d->t.hp_candidate_offset, 8);
+    l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
     l.ar_L = pick(d->t.ar_chunk, 4096);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
     l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
@@ -1237,7 +1282,8 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_U = take(cc * (l.hp_R + 1) * 16);
         l.o_hp_E = take(cc * (l.hp_R + 1) * 16);
         l.o_hp_sel = take(cc);
-        l.o_hp_done = take(cc);
+        l.o_hp_done = take(cc * l.hp_S);
+        l.o_hp_M = take(cc * l.hp_R * (l.hp_S - 1) * 16 + 16);
         l.o_hp_nxt = take(cc * (l.hp_R + 1));
         l.o_hp_guess = take(cc);
         l.o_hp_pos = take(n_clips * g.C * 4);
@@ -1428,13 +1474,15 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.E = reinterpret_cast<uint32_t*>(ws + l.o_hp_E);
         hc.sel = reinterpret_cast<int8_t*>(ws + l.o_hp_sel);
         hc.done = reinterpret_cast<uint8_t*>(ws + l.o_hp_done);
+        hc.S = l.hp_S;
+        hc.M = reinterpret_cast<uint32_t*>(ws + l.o_hp_M);
         hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
         hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         const int64_t nA = chains * l.hp_chunks * hc.R;
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
-        const int64_t nC = chains * l.hp_chunks;
+        const int64_t nC = chains * l.hp_chunks * l.hp_S;
         if (phase != 2) {
             OFP_HIP(hipMemsetAsync(hc.pos, 0, chains * 4, stream));
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);

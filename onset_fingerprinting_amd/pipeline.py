@@ -103,7 +103,7 @@ class FingerprintPipeline:
                    mel=mel, logits=logits.reshape(n_clips, C, -1, logits.shape[-1]),
                    info=self.detector.last_info)
         if timed:
-            torch.cuda.synchronize(self.device)
+            main.synchronize()  # this pipeline's streams only: other pipelines may be in flight
             e = self._ev
             out["spectral_ms"] = dict(stft=e[0].elapsed_time(e[1]), mel=e[1].elapsed_time(e[2]),
                                       mlp=e[2].elapsed_time(e[3]))
