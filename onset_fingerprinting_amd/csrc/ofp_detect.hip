@@ -1236,15 +1236,28 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // longest follower time constant in samples (coefficient = 1/samples)
     const float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
     const double tau = cmin > 0 ? 1.0 / cmin : 1.0;
-    l.hp_L = pick(d->t.hp_chunk, 8192);
+    // Defaults are for the latency regime (few chains: C2 has 8): many short chunks, 16 candidates
+    // each, so that every SIMD holds about one wave.  A big batch (C3: 64 x 600 s, C4: 2048 chains)
+    // has parallelism to spare and pays for every redundant step instead, so candidates are traded
+    // for chunk length until the launch is about two waves per SIMD.
+    const int64_t chains = n_clips * g.C;
+    const int64_t lane_budget = 2 * 4 * 64 * (int64_t)d->n_cus;
+    int64_t hpL = 8192, hpR = 16, arL = 4096, mmL = 8192;
+    if (d->t.hp_chunk <= 0 && d->t.hp_candidates <= 0) {
+        if (chains * cdiv(g.V, hpL) * hpR > lane_budget) hpR = 8;  // fewer leave too many chain breaks
+        while (hpL < 65536 && chains * cdiv(g.V, hpL) * hpR > lane_budget) hpL *= 2;
+    }
+    while (arL < 32768 && chains * cdiv(g.U, arL) > lane_budget) arL *= 2;
+    while (mmL < 32768 && chains * cdiv(g.U, mmL) > lane_budget) mmL *= 2;
+    l.hp_L = pick(d->t.hp_chunk, hpL);
     l.hp_W = pick_warm(d->t.hp_warm, 49152);
-    l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, 16)));
+    l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, hpR)));
     // candidate starts 8 samples apart: distinct rounding histories (measured over nine inputs: as
     // few verification rounds as with ~1000), yet the 16 lanes of a chunk read 4 cache lines per
     // load instead of 16 and no lane runs much longer than W + L.  < 0: common start, see kernel.
     l.hp_delta = d->t.hp_candidate_offset < 0 ? 0 : pick(d->t.hp_candidate_offset, 8);
     l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
-    l.ar_L = pick(d->t.ar_chunk, 4096);
+    l.ar_L = pick(d->t.ar_chunk, arL);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
     l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
     // symmetric slow follower: closed-form guess (k_ar_sym_local/combine) instead of the
@@ -1262,7 +1275,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.ar_W = align_up(l.ar_W, l.ar_L);  // the guess is available at chunk boundaries
         l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(16.0 * tau_s, 8.0e6), 1024));
     }
-    l.mm_L = pick(d->t.mm_chunk, 8192);
+    l.mm_L = pick(d->t.mm_chunk, mmL);
     l.mm_W = pick_warm(d->t.mm_warm, 49152);
     l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
     l.ar_chunks = std::max<int64_t>(1, cdiv(g.U, l.ar_L));

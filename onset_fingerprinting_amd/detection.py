@@ -151,7 +151,7 @@ class BatchDetector:
         B = self.block_size
         warm = int(0.5 * self.sr) if warm is None else int(warm)
         nb = N // B
-        cap = int(cap_per_clip) if cap_per_clip is not None else max(1, min(nb * C, 1 << 16))
+        cap = int(cap_per_clip) if cap_per_clip is not None else max(1, min(nb * C, 1 << 20))
         ws = self.reserve(n_clips, N, warm)
         if out is None:
             out = {

@@ -60,7 +60,7 @@ class FingerprintPipeline:
             dev = self.device
             self._bufs = dict(
                 key=key,
-                det=dict(records=torch.empty((n_clips, max(1, min(nb * C, 1 << 16)), 16), dtype=torch.uint8, device=dev),
+                det=dict(records=torch.empty((n_clips, max(1, min(nb * C, 1 << 20)), 16), dtype=torch.uint8, device=dev),
                          counts=torch.zeros(n_clips, dtype=torch.int64, device=dev),
                          rel=torch.empty((n_clips, nb * self.hop, C), dtype=torch.float32, device=dev)),
                 power=torch.empty((n_clips, C, H, bins), dtype=torch.float32, device=dev),

@@ -1,0 +1,74 @@
+"""BASELINE config C3 at full size on one MI355X: 64 ch x 600 s @ 48 kHz, 2048/512, detect +
+rFFT |X|^2 + 40 mel + FCNN(40-10-10-10-8), checked against the CPU oracle (test infrastructure):
+onset indices and the relative envelope over the WHOLE clip (exact), mel / logits on two channels.
+Prints one JSON line.
+
+    python tools/run_c3.py [seconds=600] [channels=64] [tuning json]
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch
+
+import oracle
+from onset_fingerprinting_amd import synth
+from onset_fingerprinting_amd.pipeline import FingerprintPipeline, seeded_fcnn
+
+SR, NFFT, HOP, NMELS = 48000, 2048, 512, 40
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+t0 = time.perf_counter()
+x = synth.c3_stream(secs, C, SR, seed=2)
+print(f"generated {x.shape} in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
+pipe = FingerprintPipeline(C, NFFT, HOP, SR, NMELS)
+if len(sys.argv) > 3:  # experiments: JSON dict of ofp_detect_tuning fields
+    pipe.detector.set_tuning(**json.loads(sys.argv[3]))
+frames = C * pipe.n_frames(x.shape[0])
+out = pipe.run(xd)
+torch.cuda.synchronize()
+best = None
+for _ in range(3):
+    t0 = time.perf_counter()
+    out = pipe.run(xd, timed=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+print(f"GPU step {best * 1e3:.1f} ms", file=sys.stderr, flush=True)
+counts = int(out["counts"][0])
+assert counts <= out["cap"], (counts, out["cap"])
+rec = out["records"][0, :counts].cpu().numpy().view(np.dtype([("clip", np.int32), ("channel", np.int32),
+                                                              ("sample", np.int64)])).reshape(-1)
+t0 = time.perf_counter()
+ch, on, rel = oracle.detect_onsets_amplitude(x, block_size=HOP, sr=SR)
+t_cpu = time.perf_counter() - t0
+print(f"oracle detector {t_cpu:.1f} s", file=sys.stderr, flush=True)
+idx_ok = np.array_equal(rec["channel"], np.array(ch)) and np.array_equal(rec["sample"], np.array(on))
+g_rel = out["rel"][0].cpu().numpy()
+rel_ok = bool(np.array_equal(g_rel.view(np.uint32), rel.view(np.uint32)))
+# spectral branch on two channels, first 3000 frames
+sd = {k: v.numpy() for k, v in seeded_fcnn(NMELS, 8).state_dict().items()}
+fb = oracle.mel_filterbank(SR, NFFT, NMELS).astype(np.float64)
+H = 3000
+n = NFFT + (H - 1) * HOP
+errs_mel, errs_log = [], []
+for c in (0, C - 1):
+    P = oracle.dense_power_frames(np.ascontiguousarray(x[:n, c:c + 1]), NFFT, HOP)[0]
+    mel = P @ fb.T
+    lg = oracle.fcnn_forward(sd, mel)
+    gm = out["mel"][0, c, :H].cpu().numpy()
+    gl = out["logits"][0, c, :H].cpu().numpy()
+    errs_mel.append(float(np.abs(gm - mel).max() / mel.max()))
+    errs_log.append(float(np.abs(gl - lg).max() / np.abs(lg).max()))
+print(json.dumps(dict(
+    workload=f"C3: {C} ch x {secs:g} s @ 48 kHz, {NFFT}/{HOP}, detect + rFFT + {NMELS} mel + FCNN", frames=frames,
+    gpu_ms=round(best * 1e3, 2), frames_per_s=round(frames / best), onsets=counts,
+    stage_ms={k: round(v, 2) for k, v in out["info"]["stage_ms"].items()},
+    spectral_ms={k: round(v, 2) for k, v in out["spectral_ms"].items()},
+    passes={k: out["info"][k] for k in ("hp_passes", "ar_passes", "mm_passes", "repaired")},
+    oracle_detector_s=round(t_cpu, 1), onset_indices_exact=bool(idx_ok), rel_bit_exact=rel_ok,
+    mel_max_rel_err=max(errs_mel), logits_max_rel_err=max(errs_log))))
