@@ -968,47 +968,135 @@ struct ScanArgs {
     int64_t nb, n_clips;
     int32_t* first_cross;  // [clips][nb][C]: index or -1
     int32_t* last_below;   // [clips][nb][C]: index or -1
+    uint32_t* vflag;       // [clips][nb]: some channel has an upward crossing in this block (zeroed by the host)
 };
 
+// One wave per (chain, block), lanes over the rows of the block (coalesced); the first crossing
+// and the last row below `off` come out of two ballots per 64 rows.
 __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
     const int C = a.g.C, B = a.g.B;
+    const int lane = threadIdx.x & 63;
     const int64_t total = a.n_clips * a.nb * C;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    // thread order (clip, c, block): neighbouring lanes read neighbouring blocks of one series
-    const int64_t j = id % a.nb;
-    const int64_t chain = id / a.nb;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // item order (clip, c, block): consecutive waves read consecutive blocks of one series
+    for (int64_t id = wave0; id < total; id += n_waves) {
+        const int64_t j = id % a.nb;
+        const int64_t chain = id / a.nb;
+        const int c = (int)(chain % C);
+        const int64_t clip = chain / C;
+        const int64_t oi = (clip * a.nb + j) * C + c;
+        float on, off;
+        double on0;
+        if (a.manual) {
+            on = a.on_f[c];
+            on0 = a.on_d[c];
+            off = a.off_f[c];
+        } else {
+            const float mn = a.thr_mn[oi], mx = a.thr_mx[oi];
+            const float t1 = mx * a.on_f[c];
+            on = t1 + mn;  // detection.py:763
+            on0 = (double)on;
+            const float t2 = mx * a.off_f[c];
+            off = t2 + mn;  // detection.py:787
+        }
+        const float* r = a.rel + chain * a.g.U + a.g.n_wb + j * B;
+        // detection.py:769: row 0 compares prev_values (float64 copy of the previous block's last
+        // row; zeros before the first main block) with the threshold
+        float carry = (j == 0) ? 0.0f : r[-1];
+        int first = -1, last = -1;
+        for (int t0 = 0; t0 < B; t0 += 64) {
+            const int t = t0 + lane;
+            const float v = t < B ? r[t] : 0.0f;
+            float prev = __shfl_up(v, 1);
+            if (lane == 0) prev = carry;
+            const bool below_before = (t == 0) ? ((double)prev < on0) : (prev < on);
+            const unsigned long long mc = __ballot(t < B && v > on && below_before);
+            const unsigned long long mb = __ballot(t < B && v < off);
+            if (first < 0 && mc) first = t0 + __builtin_ctzll(mc);
+            if (mb) last = t0 + 63 - __builtin_clzll(mb);
+            carry = __shfl(v, 63);
+        }
+        if (lane == 0) {
+            a.first_cross[oi] = first;
+            a.last_below[oi] = last;
+            if (first >= 0) a.vflag[clip * a.nb + j] = 1u;  // every writer stores the same value
+        }
+    }
+}
+
+// pc[clip][j][c]: the last block <= j of channel c that holds a row below the off threshold
+// (-1: none yet).  One wave per (clip, channel), 64 blocks per step.
+__global__ __launch_bounds__(64) void k_last_clear(const int32_t* __restrict__ lb, int32_t* __restrict__ pc,
+                                                   int64_t nb, int C) {
+    const int64_t chain = blockIdx.x;
     const int c = (int)(chain % C);
     const int64_t clip = chain / C;
-    const int64_t oi = (clip * a.nb + j) * C + c;
-    float on, off;
-    double on0;
-    if (a.manual) {
-        on = a.on_f[c];
-        on0 = a.on_d[c];
-        off = a.off_f[c];
-    } else {
-        const float mn = a.thr_mn[oi], mx = a.thr_mx[oi];
-        const float t1 = mx * a.on_f[c];
-        on = t1 + mn;  // detection.py:763
-        on0 = (double)on;
-        const float t2 = mx * a.off_f[c];
-        off = t2 + mn;  // detection.py:787
+    const int lane = threadIdx.x;
+    int carry = -1;
+    for (int64_t j0 = 0; j0 < nb; j0 += 64) {
+        const int64_t j = j0 + lane;
+        int v = (j < nb && lb[(clip * nb + j) * C + c] >= 0) ? (int)j : -1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v = max(v, t);
+        }
+        v = max(v, carry);
+        if (j < nb) pc[(clip * nb + j) * C + c] = v;
+        carry = __shfl(v, 63);
     }
-    const float* r = a.rel + chain * a.g.U + a.g.n_wb + j * B;
-    // detection.py:769: row 0 compares prev_values (float64 copy of the previous block's last
-    // row; zeros before the first main block) with the threshold
-    const float prev = (j == 0) ? 0.0f : r[-1];
-    bool below_before = (double)prev < on0;
-    int first = -1, last = -1;
-    for (int t = 0; t < B; ++t) {
-        const float v = r[t];
-        if (first < 0 && v > on && below_before) first = t;
-        if (v < off) last = t;
-        below_before = v < on;
+}
+
+// The state machine only has to stop at blocks where some channel crosses its on threshold
+// upwards ("visits"): everywhere else no onset can fire, the cooldown counters move in closed
+// form and a latched channel is released iff a block in between holds a row below its off
+// threshold -- which pc[] answers.  k_visits compacts, per clip and in order, the visited blocks
+// and gathers what the machine needs there: fc, lb of the block and pc of the block before.
+struct VisArgs {
+    const uint32_t* vflag;
+    const int32_t *fc, *lb, *pc;  // [clips][nb][C]
+    int64_t nb;
+    int C;
+    int32_t* vis_j;               // [clips][nb] visited block indices
+    int32_t *vfc, *vlb, *vpc;     // [clips][nb][C] compacted records
+    int32_t* nv;                  // [clips]
+};
+
+__global__ __launch_bounds__(256) void k_visits(VisArgs a) {
+    __shared__ int s_w[4];
+    const int64_t clip = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    int base = 0;
+    for (int64_t j0 = 0; j0 < a.nb; j0 += 256) {
+        const int64_t j = j0 + threadIdx.x;
+        const bool f = j < a.nb && a.vflag[clip * a.nb + j] != 0u;
+        const unsigned long long m0 = __ballot(f);
+        if (lane == 0) s_w[wave] = __popcll(m0);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) woff += s_w[w];
+            tot += s_w[w];
+        }
+        unsigned long long m = m0;
+        while (m) {  // the wave copies one visited block's record at a time, lanes over channels
+            const int l = __builtin_ctzll(m);
+            const int64_t jj = j0 + wave * 64 + l;
+            const int64_t pos = clip * a.nb + base + woff + __popcll(m0 & ((1ull << l) - 1ull));
+            if (lane == 0) a.vis_j[pos] = (int32_t)jj;
+            for (int c = lane; c < C; c += 64) {
+                const int64_t src = (clip * a.nb + jj) * C + c;
+                a.vfc[pos * C + c] = a.fc[src];
+                a.vlb[pos * C + c] = a.lb[src];
+                a.vpc[pos * C + c] = jj > 0 ? a.pc[src - C] : -1;
+            }
+            m &= m - 1;
+        }
+        base += tot;
+        __syncthreads();
     }
-    a.first_cross[oi] = first;
-    a.last_below[oi] = last;
+    if (threadIdx.x == 0) a.nv[clip] = base;
 }
 
 // ---- hysteresis / cooldown state machine over the blocks of one clip
@@ -1016,17 +1104,19 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
 struct SmArgs {
     Geom g;
     int64_t nb, n_clips, cap, cooldown;
-    const int32_t* first_cross;
-    const int32_t* last_below;
-    ofp_onset* records;  // [clips][cap]
-    int64_t* counts;     // [clips]
-    int32_t clip_base;   // added to record.clip
+    const int32_t* vis_j;            // [clips][nb] visited blocks, in order
+    const int32_t *vfc, *vlb, *vpc;  // [clips][nb][C] their records (k_visits)
+    const int32_t* nv;               // [clips] number of visits
+    ofp_onset* records;              // [clips][cap]
+    int64_t* counts;                 // [clips]
+    int32_t clip_base;               // added to record.clip
 };
 
-// Event-driven: the crossing tables are staged through LDS a tile of blocks at a
-// time (coalesced, one tile ahead); while no channel is latched the wave jumps
-// straight to the next block that holds a candidate crossing and advances the
-// cooldown counters in closed form over the skipped blocks.
+// Visit-driven: the wave walks the compacted list of blocks that hold an upward crossing, a tile
+// of visits at a time through LDS (coalesced, one tile ahead).  Between two visits nothing can
+// fire: the cooldown counters advance in closed form (:780) and a latched channel is released iff
+// some skipped block holds a row below its off threshold (:784-791 with on_indices.max() == 0),
+// i.e. iff pc of the block before this visit is later than the previous visit.
 constexpr int SM_NPL = 16;  // table entries per lane per tile (TB*C <= 64*SM_NPL)
 
 __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
@@ -1034,12 +1124,14 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
     const int C = a.g.C, B = a.g.B;
     const int64_t clip = blockIdx.x;
     const int lane = threadIdx.x;
-    const int TB = max(1, min(64, (64 * SM_NPL) / C));  // blocks per tile
+    const int TB = max(1, min(64, (64 * SM_NPL) / C));  // visits per tile
     int64_t* deb = reinterpret_cast<int64_t*>(smem);          // [C]
     int32_t* onidx = reinterpret_cast<int32_t*>(deb + C);     // [C]
     int32_t* t_fc = onidx + C;                                // [TB*C]
     int32_t* t_lb = t_fc + TB * C;                            // [TB*C]
-    uint8_t* state = reinterpret_cast<uint8_t*>(t_lb + TB * C);  // [C]
+    int32_t* t_pc = t_lb + TB * C;                            // [TB*C]
+    int32_t* t_j = t_pc + TB * C;                             // [64]
+    uint8_t* state = reinterpret_cast<uint8_t*>(t_j + 64);    // [C]
     uint8_t* onflag = state + C;                              // [C]
     for (int c = lane; c < C; c += 64) {
         deb[c] = 0;
@@ -1047,17 +1139,23 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
     }
     int64_t count = 0;
     ofp_onset* rec = a.records + clip * a.cap;
-    const int32_t* fc_g = a.first_cross + clip * a.nb * C;
-    const int32_t* lb_g = a.last_below + clip * a.nb * C;
-    int32_t rf[SM_NPL], rl[SM_NPL];
-    auto load_tile = [&](int64_t j0) {
-        const int64_t n = min<int64_t>(TB, a.nb - j0) * C;
+    const int64_t nvis = a.nv[clip];
+    const int32_t* fc_g = a.vfc + clip * a.nb * C;
+    const int32_t* lb_g = a.vlb + clip * a.nb * C;
+    const int32_t* pc_g = a.vpc + clip * a.nb * C;
+    const int32_t* vj_g = a.vis_j + clip * a.nb;
+    int32_t rf[SM_NPL], rl[SM_NPL], rp[SM_NPL], rj = 0;
+    auto load_tile = [&](int64_t k0) {
+        const int64_t nvt = min<int64_t>(TB, nvis - k0);
+        const int64_t n = nvt * C;
 #pragma unroll
         for (int i = 0; i < SM_NPL; ++i) {
             const int64_t e = lane + 64 * i;
-            rf[i] = e < n ? fc_g[j0 * C + e] : -1;
-            rl[i] = e < n ? lb_g[j0 * C + e] : -1;
+            rf[i] = e < n ? fc_g[k0 * C + e] : -1;
+            rl[i] = e < n ? lb_g[k0 * C + e] : -1;
+            rp[i] = e < n ? pc_g[k0 * C + e] : -1;
         }
+        rj = lane < nvt ? vj_g[k0 + lane] : 0;
     };
     auto put_tile = [&]() {
 #pragma unroll
@@ -1066,43 +1164,37 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
             if (e < TB * C) {
                 t_fc[e] = rf[i];
                 t_lb[e] = rl[i];
+                t_pc[e] = rp[i];
             }
         }
+        t_j[lane] = rj;
     };
-    bool any_latched = false;  // wave-uniform: some channel has state == 1
-    if (a.nb > 0) load_tile(0);
-    for (int64_t j0 = 0; j0 < a.nb; j0 += TB) {
+    int jp = -1;  // previous visited block
+    if (nvis > 0) load_tile(0);
+    for (int64_t k0 = 0; k0 < nvis; k0 += TB) {
         __syncthreads();
         put_tile();
         __syncthreads();
-        if (j0 + TB < a.nb) load_tile(j0 + TB);
-        const int nblk = (int)min<int64_t>(TB, a.nb - j0);
-        // candidate blocks of this tile: any channel with an upward crossing
-        bool cand = false;
-        if (lane < nblk)
-            for (int c = 0; c < C; ++c) cand |= t_fc[lane * C + c] >= 0;
-        const unsigned long long cmask = __ballot(cand);
-        int bi = 0;
-        while (bi < nblk) {
-            if (!any_latched) {
-                const unsigned long long rest = cmask >> bi;
-                const int skip = rest ? __builtin_ctzll(rest) : (nblk - bi);
-                if (skip > 0) {  // nothing can fire: only the cooldown counters move (:780)
-                    for (int c = lane; c < C; c += 64) {
-                        int64_t d = deb[c];
-                        if (d > 0) deb[c] = d - (int64_t)B * min<int64_t>(skip, (d + B - 1) / B);
-                    }
-                    bi += skip;
-                    if (bi >= nblk) break;
-                }
-            }
-            const int64_t j = j0 + bi;
+        if (k0 + TB < nvis) load_tile(k0 + TB);
+        const int nblk = (int)min<int64_t>(TB, nvis - k0);
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int j = t_j[bi];
             const int32_t* fc = t_fc + bi * C;
             const int32_t* lb = t_lb + bi * C;
+            const int32_t* pc = t_pc + bi * C;
+            const int skipped = j - jp - 1;
             int mx = 0;
             for (int c = lane; c < C; c += 64) {
+                // the blocks skipped since the previous visit
+                int64_t d = deb[c];
+                if (skipped > 0 && d > 0) d -= (int64_t)B * min<int64_t>(skipped, (d + B - 1) / B);
+                deb[c] = d;
+                uint8_t st = state[c];
+                if (st && pc[c] > jp) st = 0;
+                state[c] = st;
+                // this block
                 int f = fc[c];
-                bool gate = !state[c] && deb[c] < 1;      // :764-768 (block-start values)
+                bool gate = !st && d < 1;                 // :764-768 (block-start values)
                 bool on = gate && f >= 0;
                 onflag[c] = on;
                 int oi = on ? f : 0;                      // :774 argmax of an all-False column is 0
@@ -1122,7 +1214,6 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
                 }
                 mx = red;
             }
-            bool latched = false;
             for (int c0 = 0; c0 < C; c0 += 64) {
                 int c = c0 + lane;
                 bool on = false;
@@ -1134,7 +1225,6 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
                     }
                     if (deb[c] > 0) deb[c] -= B;           // :780
                     if (lb[c] >= mx) state[c] = 0;         // :784-791 (any row >= mx below off)
-                    latched |= state[c] != 0;
                 }
                 unsigned long long m = __ballot(on);
                 if (on) {
@@ -1142,13 +1232,12 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
                     if (pos < a.cap) {
                         rec[pos].clip = (int32_t)clip + a.clip_base;
                         rec[pos].channel = c;
-                        rec[pos].sample = j * B + onidx[c];  // detection.py:80
+                        rec[pos].sample = (int64_t)j * B + onidx[c];  // detection.py:80
                     }
                 }
                 count += __popcll(m);
             }
-            any_latched = __ballot(latched) != 0ull;
-            ++bi;
+            jp = j;
         }
     }
     if (lane == 0) a.counts[clip] = count;
@@ -1214,7 +1303,7 @@ struct Layout {
     int tu;  // time steps per transpose tile
     // byte offsets
     int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
-        o_thr_mn, o_thr_mx, o_first, o_last, o_flags, total;
+        o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, total;
 };
 
 int64_t pick(int64_t user, int64_t dflt) { return user > 0 ? user : dflt; }
@@ -1308,6 +1397,11 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_thr_mx = take(n_clips * l.nb * g.C * 4);
     l.o_first = take(n_clips * l.nb * g.C * 4);
     l.o_last = take(n_clips * l.nb * g.C * 4);
+    l.o_vflag = take(n_clips * l.nb * 4);
+    l.o_pc = take(n_clips * l.nb * g.C * 4);
+    l.o_visj = take(n_clips * l.nb * 4);
+    l.o_vrec = take(3 * n_clips * l.nb * g.C * 4);
+    l.o_nv = take(n_clips * 4);
     l.o_flags = take(256);
     l.total = o;
     return l;
@@ -1623,25 +1717,51 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sa.n_clips = n_clips;
     sa.first_cross = reinterpret_cast<int32_t*>(ws + l.o_first);
     sa.last_below = reinterpret_cast<int32_t*>(ws + l.o_last);
+    sa.vflag = reinterpret_cast<uint32_t*>(ws + l.o_vflag);
     {
         const int64_t total = n_clips * l.nb * g.C;
-        hipLaunchKernelGGL(k_block_scan, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, sa);
+        OFP_HIP(hipMemsetAsync(sa.vflag, 0, n_clips * l.nb * 4, stream));
+        const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
+        hipLaunchKernelGGL(k_block_scan, dim3(bs_grid), dim3(256), 0, stream, sa);
         OFP_LAUNCH_CHECK("k_block_scan");
     }
+    VisArgs va;
+    va.vflag = sa.vflag;
+    va.fc = sa.first_cross;
+    va.lb = sa.last_below;
+    int32_t* pc = reinterpret_cast<int32_t*>(ws + l.o_pc);
+    va.pc = pc;
+    va.nb = l.nb;
+    va.C = g.C;
+    va.vis_j = reinterpret_cast<int32_t*>(ws + l.o_visj);
+    va.vfc = reinterpret_cast<int32_t*>(ws + l.o_vrec);
+    va.vlb = va.vfc + n_clips * l.nb * g.C;
+    va.vpc = va.vlb + n_clips * l.nb * g.C;
+    va.nv = reinterpret_cast<int32_t*>(ws + l.o_nv);
+    if (l.nb > 0) {
+        hipLaunchKernelGGL(k_last_clear, dim3((unsigned)chains), dim3(64), 0, stream, (const int32_t*)sa.last_below, pc,
+                           l.nb, g.C);
+        OFP_LAUNCH_CHECK("k_last_clear");
+    }
+    hipLaunchKernelGGL(k_visits, dim3((unsigned)n_clips), dim3(256), 0, stream, va);
+    OFP_LAUNCH_CHECK("k_visits");
     SmArgs sm;
     sm.g = g;
     sm.nb = l.nb;
     sm.n_clips = n_clips;
     sm.cap = cap;
     sm.cooldown = p.cooldown;
-    sm.first_cross = sa.first_cross;
-    sm.last_below = sa.last_below;
+    sm.vis_j = va.vis_j;
+    sm.vfc = va.vfc;
+    sm.vlb = va.vlb;
+    sm.vpc = va.vpc;
+    sm.nv = va.nv;
     sm.records = d_records;
     sm.counts = d_counts;
     sm.clip_base = 0;
     {
         const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
-        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)2 * tb * g.C * 4 + 16;
+        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)3 * tb * g.C * 4 + 64 * 4 + 16;
         if (lds > 65536)
             OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_state_machine),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
