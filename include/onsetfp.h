@@ -300,6 +300,26 @@ int ofp_fix_onsets(const float* d_audio, int64_t n_clips, int64_t n_samples, int
                    int32_t cutoff, int32_t tol, int32_t shift, int32_t max_section, int32_t* d_status, void* d_ws,
                    int64_t ws_bytes, void* stream);
 
+/* ---- spectral-flux onset detector (detection.py:89-128) --------------
+ * The STFT is ofp_stft_power on the centre-padded signal (librosa.stft, center=True).
+ *   ofp_spectral_flux: d_power [n_frames][n_bins] -> d_oe [n_frames-1] =
+ *     mean_k max(0, w_k sqrt(P[t+1][k]) - w_k sqrt(P[t][k]))   (detection.py:106-110; d_weight is
+ *     the normalised A-weighting of :105-106)
+ *   ofp_select_rank: the value of ascending rank `rank` among n non-negative floats (the order
+ *     statistics np.percentile interpolates, :111); d_out [1]
+ *   ofp_scale_inverse: d_x[i] /= d_scale[0]
+ *   ofp_peak_pick: librosa.util.peak_pick (:113-121): i is a peak iff x[i] == max(x[i-pre_max :
+ *     i+post_max]), x[i] >= mean(x[i-pre_avg : i+post_avg]) + delta and i - previous peak > wait;
+ *     d_peaks [cap] int64 indices, d_count [1] (may exceed cap), d_flags [n] scratch.
+ * librosa is not available to pin these against: restated from its published definition. */
+int ofp_spectral_flux(const float* d_power, int64_t n_frames, int32_t n_bins, const float* d_weight, float* d_oe,
+                      void* stream);
+int ofp_select_rank(const float* d_v, int64_t n, int64_t rank, float* d_out, void* stream);
+int ofp_scale_inverse(float* d_x, int64_t n, const float* d_scale, void* stream);
+int ofp_peak_pick(const float* d_x, int64_t n, int32_t pre_max, int32_t post_max, int32_t pre_avg, int32_t post_avg,
+                  float delta, int64_t wait, int64_t* d_peaks, int64_t cap, int64_t* d_count, uint8_t* d_flags,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

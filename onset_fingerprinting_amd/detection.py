@@ -373,7 +373,72 @@ def detect_onsets(x: np.ndarray, sr: int = 96000, method="amp"):
     """detection.py:12-16."""
     if method == "amp":
         return detect_onsets_amplitude(x, sr=sr)
-    raise NotImplementedError("detect_onsets_spectral is outside the accelerated hot path (SURVEY.md 8f N1)")
+    return detect_onsets_spectral(x, sr=sr)
+
+
+def a_weighting(frequencies, min_db=-80.0):
+    """librosa.A_weighting as published (IEC 61672 constants), used at detection.py:105."""
+    f_sq = np.asanyarray(frequencies, dtype=np.float64) ** 2.0
+    const = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+    with np.errstate(divide="ignore"):
+        w = 2.0 + 20.0 * (np.log10(const[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + const[0])
+                          - np.log10(f_sq + const[1]) - 0.5 * np.log10(f_sq + const[2])
+                          - 0.5 * np.log10(f_sq + const[3]))
+    return w if min_db is None else np.maximum(min_db, w)
+
+
+def detect_onsets_spectral(x: np.ndarray, n_fft: int = 256, hop: int = 32, sr: int = 96000,
+                           return_oe: bool = False, device=0):
+    """detection.py:89-128: A-weighted positive spectral flux, normalised by its 99.9th
+    percentile, peak-picked; returns peak sample positions (and the onset envelope).
+
+    Every array step runs on the GPU (centred STFT power, flux, order statistics, peak picking).
+    PARITY UNPINNED: the reference calls librosa (stft, A_weighting, util.peak_pick), which is not
+    installable here; those three are restated from librosa's published definitions
+    (stft: center=True with zero padding, periodic Hann, n_fft-long window)."""
+    from .data import stft_power_dense
+    L = _lib.lib()
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    n = len(x)
+    xp = torch.zeros(n + 2 * (n_fft // 2), dtype=torch.float32, device=dev)
+    xp[n_fft // 2:n_fft // 2 + n] = torch.from_numpy(x).to(dev)
+    power = stft_power_dense(xp.reshape(1, -1, 1), n_fft, hop)[0, 0]      # [T, bins], T = 1 + n // hop
+    T, bins = power.shape
+    freq = np.fft.fftfreq(n_fft, 1 / sr)[:bins]                           # :97 (last bin is -sr/2)
+    aw = a_weighting(freq)
+    w = torch.from_numpy(((aw - aw.min()) / np.abs(aw.min())).astype(np.float32)).to(dev)  # :105-106
+    st = _stream_ptr(dev)
+    m = max(T - 1, 0)
+    oe = torch.zeros(max(m, 1), dtype=torch.float32, device=dev)
+    if m == 0:
+        return (np.zeros(0, np.int64), np.zeros(0, np.float32)) if return_oe else np.zeros(0, np.int64)
+    check(L.ofp_spectral_flux(power.data_ptr(), T, bins, w.data_ptr(), oe.data_ptr(), st), "ofp_spectral_flux")
+    # np.percentile(oe, 99.9), linear interpolation between two order statistics (:111)
+    pos = 0.999 * (m - 1)
+    lo = int(np.floor(pos))
+    hi = min(lo + 1, m - 1)
+    v = torch.empty(2, dtype=torch.float32, device=dev)
+    check(L.ofp_select_rank(oe.data_ptr(), m, lo, v.data_ptr(), st), "ofp_select_rank")
+    check(L.ofp_select_rank(oe.data_ptr(), m, hi, v.data_ptr() + 4, st), "ofp_select_rank")
+    a, b = (float(t) for t in v.cpu())
+    t = pos - lo
+    p = a + (b - a) * t if t < 0.5 else b - (b - a) * (1 - t)
+    scale = torch.tensor([p], dtype=torch.float32, device=dev)
+    check(L.ofp_scale_inverse(oe.data_ptr(), m, scale.data_ptr(), st), "ofp_scale_inverse")
+    # librosa.util.peak_pick arguments of :113-121
+    pre_max, post_max = int(0.12 * sr // hop), int(0.01 * sr // hop)
+    pre_avg, post_avg = int(0.12 * sr // hop), int(0.01 * sr // hop + 1)
+    wait = int(sr * 0.07 // hop)
+    peaks = torch.empty(m, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    flags = torch.empty(m, dtype=torch.uint8, device=dev)
+    check(L.ofp_peak_pick(oe.data_ptr(), m, pre_max, max(post_max, 1), pre_avg, max(post_avg, 1), 0.1, wait,
+                          peaks.data_ptr(), m, count.data_ptr(), flags.data_ptr(), st), "ofp_peak_pick")
+    k = int(count.cpu()[0])
+    out = peaks[:k].cpu().numpy() * hop  # :124
+    return (out, oe.cpu().numpy()) if return_oe else out
 
 
 def detect_onsets_amplitude(

@@ -37,3 +37,4 @@ from .spectral import (  # noqa: F401
 from .classifier import cccnn_forward, cnn_forward, fcnn_forward  # noqa: F401
 from .groups import find_onset_groups, group_windows  # noqa: F401
 from .xcorr import adjust_onset, cross_correlation_lag, fix_onsets, lag_window, xcorr_slice  # noqa: F401
+from .spectral_onsets import detect_onsets_spectral, librosa_stft_mag, peak_pick  # noqa: F401
