@@ -612,6 +612,8 @@ struct HpCand {
     uint32_t* M;      // [clips][chunks][C][R][S-1][4] those states
     uint8_t* nxt;     // [clips][chunks][C][R+1] slot of chunk k matching E[k-1][r], 255 none
     uint8_t* guessed; // [clips][chunks][C] sel[] is an unverified plurality guess (see k_hp_resolve)
+    int8_t* ran;      // [clips][chunks][C] slot whose trajectory produced the chunk's output (R: whole run
+                      // from the true start state): lets a re-walk keep outputs whose start did not change
     int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
                       // unverified guesses
     int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
@@ -658,6 +660,7 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
         a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
         for (int sb = 0; sb < a.S; ++sb) a.done[((clip * st.n_chunks + k) * C + c) * a.S + sb] = 0;
         a.guessed[(clip * st.n_chunks + k) * C + c] = 0;
+        a.ran[(clip * st.n_chunks + k) * C + c] = -2;
         a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
     }
     HpStep s;
@@ -743,7 +746,8 @@ __device__ int hp_plurality(const HpCand& a, int64_t clip, int64_t k, int c) {
 // invalidated and walked again.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     __shared__ uint8_t tile[64 * (HP_MAXR + 1)];
-    __shared__ int8_t stile[64];
+    __shared__ int8_t stile[64], rtile[64];
+    __shared__ uint8_t redo[64];
     const int C = a.st.g.C, R1 = a.R + 1;
     const int64_t chain = blockIdx.x;  // clip*C + c
     const int c = (int)(chain % C);
@@ -774,8 +778,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             if (k == wrong) {
                 a.sel[ci] = (int8_t)a.R;
             } else {
-                a.sel[ci] = -1;
-                for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+                a.sel[ci] = -1;  // walked again below; outputs are dropped only where the start changes
             }
         }
         if (lane == 0) a.pos[chain] = (int32_t)(wrong + 1);
@@ -796,7 +799,11 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             const int bk = i / R1, r = i % R1;
             tile[i] = a.nxt[(((clip * nk + k0 + bk) * C + c) * R1) + r];
         }
-        if (lane < nblk) stile[lane] = a.sel[(clip * nk + k0 + lane) * C + c];
+        if (lane < nblk) {
+            stile[lane] = a.sel[(clip * nk + k0 + lane) * C + c];
+            rtile[lane] = a.ran[(clip * nk + k0 + lane) * C + c];
+            redo[lane] = 0;
+        }
         __syncthreads();
         int bk = 0;  // uniform: next chunk of the tile to visit
         while (bk < nblk) {
@@ -809,6 +816,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
                         if (m == 255) { brk = bk; break; }
                         s = m;
                         stile[bk] = (int8_t)s;
+                        if (rtile[bk] != s) redo[bk] = 1;  // output (if any) came from another start
                     }
                     cur = s;
                 }
@@ -817,6 +825,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             if (brk < 0) break;
             // break: continue from the plurality end state, if there is one (whole wave)
             const int gs = hp_plurality(a, clip, k0 + brk, c);
+            if (lane == 0) redo[brk] = 1;  // a break is run whole from its (new) true start
             if (gs < 0) {
                 stuck = true;
                 reached = k0 + brk;
@@ -831,7 +840,12 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             bk = brk + 1;
         }
         __syncthreads();
-        if (lane < nblk) a.sel[(clip * nk + k0 + lane) * C + c] = stile[lane];
+        if (lane < nblk) {
+            const int64_t ci = (clip * nk + k0 + lane) * C + c;
+            a.sel[ci] = stile[lane];
+            if (redo[lane])
+                for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+        }
     }
     if (lane == 0) {
         a.pos[chain] = (int32_t)reached;
@@ -901,8 +915,10 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
         }
     }
     if (whole) {
+        a.ran[ci] = (int8_t)a.R;
         for (int q = 0; q < a.S; ++q) a.done[ci * a.S + q] = 1;
     } else {
+        if (sb == 0) a.ran[ci] = (int8_t)own;
         a.done[ci * a.S + sb] = 1;
     }
 }
@@ -1302,7 +1318,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, total;
 };
 
@@ -1388,6 +1404,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_M = take(cc * l.hp_R * (l.hp_S - 1) * 16 + 16);
         l.o_hp_nxt = take(cc * (l.hp_R + 1));
         l.o_hp_guess = take(cc);
+        l.o_hp_ran = take(cc);
         l.o_hp_pos = take(n_clips * g.C * 4);
     }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
@@ -1411,7 +1428,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
 // until a pass changes nothing.  used[] has been filled by the stage's warm-up kernels.
 template <class K, class A>
 int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
-               int* d_changed, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
+               int* d_changed, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
     const int64_t words = n_threads * 2;
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
@@ -1428,9 +1445,9 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
         hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass, n_threads, (const uint32_t*)prev, next,
                            used, d_changed);
         OFP_LAUNCH_CHECK(name);
-        int changed = 0;
-        OFP_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+        OFP_HIP(hipMemcpyAsync(h_flags, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
         OFP_HIP(hipStreamSynchronize(stream));
+        const int changed = h_flags[0];
         std::swap(prev, next);
         *passes += 1;
         *repaired += changed;
@@ -1481,6 +1498,7 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
     for (int k = 0; k < 10 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_flags, 64, hipHostMallocDefault);
     if (e == hipSuccess) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -1500,6 +1518,7 @@ int ofp_detector_destroy(ofp_detector* d) {
     if (d->d_on_f) (void)hipFree(d->d_on_f);
     if (d->d_off_f) (void)hipFree(d->d_off_f);
     if (d->d_on_d) (void)hipFree(d->d_on_d);
+    if (d->h_flags) (void)hipHostFree(d->h_flags);
     for (int k = 0; k < 10; ++k)
         if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     delete d;
@@ -1585,6 +1604,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.M = reinterpret_cast<uint32_t*>(ws + l.o_hp_M);
         hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
         hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
+        hc.ran = reinterpret_cast<int8_t*>(ws + l.o_hp_ran);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         const int64_t nA = chains * l.hp_chunks * hc.R;
@@ -1608,7 +1628,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             OFP_LAUNCH_CHECK("k_hp_match");
             hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
             OFP_LAUNCH_CHECK("k_hp_resolve");
-            int flags[2] = {0, 0};  // chains stuck at a break / chains with unverified guesses
+            int* flags = d->h_flags;  // chains stuck at a break / chains with unverified guesses
             OFP_HIP(hipMemcpyAsync(flags, d_changed, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
             hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
             OFP_LAUNCH_CHECK("k_hp_run");
@@ -1659,7 +1679,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
         hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_ar_warm");
-        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, d_changed, d->t.max_passes,
+        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, d_changed, d->h_flags, d->t.max_passes,
                             stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
@@ -1697,7 +1717,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         OFP_LAUNCH_CHECK("k_mm_max");
         hipLaunchKernelGGL(k_mm_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_mm_warm");
-        int rc = run_jacobi("tracker stage", k_mm_chunk, a, nt, l.mm_chunks, used, d_changed, d->t.max_passes, stream,
+        int rc = run_jacobi("tracker stage", k_mm_chunk, a, nt, l.mm_chunks, used, d_changed, d->h_flags, d->t.max_passes, stream,
                             &info[2], &info[3]);
         if (rc != OFP_OK) return rc;
     }

@@ -15,4 +15,5 @@ struct ofp_detector {
     ofp_detect_tuning t;
     hipEvent_t ev[10] = {};     // stage timing (ofp_detect_offline h_info)
     int n_cus = 256;            // compute units of the device the detector was created on
+    int* h_flags = nullptr;     // pinned host words the pass loops copy their counters into (truly async D2H)
 };
