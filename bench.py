@@ -6,7 +6,7 @@
 One step = one pass of detect -> rFFT |X|^2 -> 40-mel -> FCNN over one batch of
 synthetic audio already resident in HBM, plus (N > 1) the RCCL all-gather that
 collates onset records.  The detector is a chain of latency-bound recurrences that
-fills a fraction of the chip, so `--inflight` steps (default 3) are in flight at a
+fills a fraction of the chip, so `--inflight` steps (default 4) are in flight at a
 time on each GPU, each on its own pipeline instance (work space, buffers, streams,
 host thread); every step is still one complete pass over one clip, steps complete and
 are gathered in order, and `config.latency_ms_per_step` reports what one step takes
@@ -18,6 +18,11 @@ not shard in time), so scaling is weak.  Rank 0 prints ONE JSON li
 import argparse
 import json
 import os
+
+# Steps in flight live on separate HIP streams; by default the runtime multiplexes all streams of a
+# process onto 4 hardware queues, which serialises unrelated steps behind each other's 2 ms kernels.
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import sys
 import time
 from pathlib import Path
@@ -78,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, help="steps (clips) processed concurrently per GPU")
+    ap.add_argument("--inflight", type=int, default=4, help="steps (clips) processed concurrently per GPU")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
     args = ap.parse_args()
 
@@ -135,11 +140,15 @@ def main():
     workers = [ThreadPoolExecutor(1) for _ in range(D)]  # worker w runs steps w, w+D, ... in order
 
     def run_steps(n, timed):
-        futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n)]
+        # at most D steps outstanding; pipeline w gets its next step only after this thread has
+        # consumed (flattened, gathered) the outputs of its previous one
+        futs = {i: workers[i % D].submit(run_step, i % D, timed) for i in range(min(D, n))}
         res = None
-        for f in futs:  # complete in step order; the collective runs on this thread
-            out, lat = f.result()
+        for i in range(n):  # complete in step order; the collective runs on this thread
+            out, lat = futs.pop(i).result()
             res = finish(out, lat, timed)
+            if i + D < n:
+                futs[i + D] = workers[i % D].submit(run_step, i % D, timed)
         return res
 
     def barrier():

@@ -1355,7 +1355,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     while (arL < 32768 && chains * cdiv(g.U, arL) > lane_budget) arL *= 2;
     while (mmL < 32768 && chains * cdiv(g.U, mmL) > lane_budget) mmL *= 2;
     l.hp_L = pick(d->t.hp_chunk, hpL);
-    l.hp_W = pick_warm(d->t.hp_warm, 49152);
+    l.hp_W = pick_warm(d->t.hp_warm, 40960);
     l.hp_R = (int)std::max<int64_t>(1, std::min<int64_t>(HP_MAXR, pick(d->t.hp_candidates, hpR)));
     // candidate starts 8 samples apart: distinct rounding histories (measured over nine inputs: as
     // few verification rounds as with ~1000), yet the 16 lanes of a chunk read 4 cache lines per
