@@ -234,9 +234,10 @@ int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float*
               float* d_y, void* stream);
 /* Conv1d (stride 1, groups 1) + bias + activation: d_x [n][cin][w] ->
  * d_y [n][cout][wout], wout = w + 2*padding - dilation*(k-1)   (model.py:84-95) */
-int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w /*[cout][cin][k]*/,
-               const float* d_b, int32_t cout, int32_t k, int32_t padding, int32_t dilation,
-               int32_t act, float* d_y, void* stream);
+int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w /*[cout][cin/groups][k]*/,
+               const float* d_b, int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t groups,
+               int32_t act, const float* d_bn_scale /*[cout] or NULL*/, const float* d_bn_shift,
+               int32_t pool /* MaxPool1d(2, 2) after the affine */, float* d_y, void* stream);
 
 /* CCCNN correlation head (model.py:524-534): d_x [n][K][V] feature maps -> d_out [n][2V-1]:
  * full auto-correlation of every map, summed over the K maps, soft-maxed over the lags. */

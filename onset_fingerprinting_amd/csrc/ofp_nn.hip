@@ -64,28 +64,40 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ x, int6
     }
 }
 
-// Conv1d, stride 1, groups 1: thread per output element
+// Conv1d (stride 1, any groups) + bias + activation, then the optional per-channel affine of an
+// eval-mode BatchNorm1d and MaxPool1d(2, 2) -- the layer of model.py:91-107 in one pass.
+// Thread per output element (after pooling).
 __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int64_t n, int cin, int w,
                                                 const float* __restrict__ wt, const float* __restrict__ b,
-                                                int cout, int k, int padding, int dilation, int act,
-                                                int wout, float* __restrict__ y) {
+                                                int cout, int k, int padding, int dilation, int groups, int act,
+                                                const float* __restrict__ bn_scale,
+                                                const float* __restrict__ bn_shift, int pool, int wout,
+                                                float* __restrict__ y) {
     const int64_t total = n * cout * wout;
+    const int cin_g = cin / groups, cout_g = cout / groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(i % wout);
         const int64_t t = i / wout;
         const int o = (int)(t % cout);
         const int64_t s = t / cout;
-        float acc = b ? b[o] : 0.0f;
-        const float* xs = x + s * cin * w;
-        const float* ws = wt + (int64_t)o * cin * k;
-        for (int ci = 0; ci < cin; ++ci) {
-            for (int kk = 0; kk < k; ++kk) {
-                int q = p - padding + kk * dilation;
-                if (q >= 0 && q < w) acc = fmaf(xs[(int64_t)ci * w + q], ws[ci * k + kk], acc);
+        const float* xs = x + (s * cin + (int64_t)(o / cout_g) * cin_g) * w;
+        const float* ws = wt + (int64_t)o * cin_g * k;
+        float best = 0.0f;
+        for (int h = 0; h <= pool; ++h) {
+            const int pc = pool ? 2 * p + h : p;  // position in the un-pooled row
+            float acc = b ? b[o] : 0.0f;
+            for (int ci = 0; ci < cin_g; ++ci) {
+                for (int kk = 0; kk < k; ++kk) {
+                    int q = pc - padding + kk * dilation;
+                    if (q >= 0 && q < w) acc = fmaf(xs[(int64_t)ci * w + q], ws[ci * k + kk], acc);
+                }
             }
+            float v = activate(acc, act);
+            if (bn_scale) v = fmaf(v, bn_scale[o], bn_shift[o]);
+            best = h == 0 ? v : fmaxf(best, v);
         }
-        y[i] = activate(acc, act);
+        y[i] = best;
     }
 }
 
@@ -169,17 +181,22 @@ int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float*
 }
 
 int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w, const float* d_b,
-               int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t act, float* d_y,
-               void* stream) {
+               int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t groups, int32_t act,
+               const float* d_bn_scale, const float* d_bn_shift, int32_t pool, float* d_y, void* stream) {
     if (n == 0) return OFP_OK;
     OFP_REQUIRE(d_x && d_w && d_y, "ofp_conv1d: NULL argument");
+    OFP_REQUIRE(groups >= 1 && cin % groups == 0 && cout % groups == 0,
+                "ofp_conv1d: groups %d must divide cin %d and cout %d", groups, cin, cout);
+    OFP_REQUIRE((d_bn_scale == nullptr) == (d_bn_shift == nullptr), "ofp_conv1d: give both bn_scale and bn_shift");
     int wout = w + 2 * padding - dilation * (k - 1);
     OFP_REQUIRE(wout >= 1, "ofp_conv1d: empty output (w=%d k=%d padding=%d dilation=%d)", w, k, padding, dilation);
+    if (pool) wout /= 2;  // MaxPool1d(kernel_size=2, stride=2), floor
+    OFP_REQUIRE(wout >= 1, "ofp_conv1d: nothing left after pooling");
     OFP_REQUIRE(act >= OFP_ACT_IDENTITY && act <= OFP_ACT_TANH, "ofp_conv1d: unknown activation %d", act);
     int64_t total = n * cout * wout;
     unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
     hipLaunchKernelGGL(k_conv1d, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n, cin, w, d_w, d_b, cout,
-                       k, padding, dilation, act, wout, d_y);
+                       k, padding, dilation, groups, act, d_bn_scale, d_bn_shift, pool ? 1 : 0, wout, d_y);
     OFP_LAUNCH_CHECK("k_conv1d");
     return OFP_OK;
 }

@@ -21,15 +21,50 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def conv1d_forward(x, weight, bias, padding, dilation, act_code):
+def conv1d_forward(x, weight, bias, padding, dilation, act_code, groups=1, bn=None, pool=False):
+    """Conv1d + bias + activation (+ eval-mode BatchNorm1d `bn` + MaxPool1d(2, 2)): the layer of
+    model.py:91-107 in one kernel."""
     L = _lib.lib()
     n, cin, w = x.shape
     cout, _, k = weight.shape
     wout = w + 2 * padding - dilation * (k - 1)
+    if pool:
+        wout //= 2
+    scale = shift = None
+    if bn is not None:  # y = (v - mean) / sqrt(var + eps) * gamma + beta, folded in double
+        inv = (bn.running_var.double() + bn.eps).rsqrt()
+        g = bn.weight.double() if bn.weight is not None else torch.ones_like(inv)
+        b = bn.bias.double() if bn.bias is not None else torch.zeros_like(inv)
+        scale = (g * inv).to(x.device, torch.float32).contiguous()
+        shift = (b - bn.running_mean.double() * g * inv).to(x.device, torch.float32).contiguous()
     out = torch.empty((n, cout, wout), dtype=torch.float32, device=x.device)
     check(L.ofp_conv1d(x.data_ptr(), n, cin, w, weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                       cout, k, padding, dilation, act_code, out.data_ptr(), _stream(x.device)), "ofp_conv1d")
+                       cout, k, padding, dilation, groups, act_code,
+                       scale.data_ptr() if scale is not None else None,
+                       shift.data_ptr() if shift is not None else None, int(bool(pool)), out.data_ptr(),
+                       _stream(x.device)), "ofp_conv1d")
     return out
+
+
+def _run_conv_stack(layers, h, to, padding, dilation, act_code, groups):
+    mods = list(layers)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv1d):
+            bn, pool, j = None, False, i + 1
+            while j < len(mods) and not isinstance(mods[j], nn.Conv1d):
+                if isinstance(mods[j], nn.BatchNorm1d):
+                    bn = mods[j]
+                elif isinstance(mods[j], nn.MaxPool1d):
+                    pool = True
+                j += 1
+            h = conv1d_forward(h, to(m.weight), to(m.bias) if m.bias is not None else None, padding, dilation,
+                               act_code, groups=groups, bn=bn, pool=pool)
+            i = j
+        else:
+            i += 1
+    return h
 
 
 class CNN(nn.Module):
@@ -37,12 +72,10 @@ class CNN(nn.Module):
                  kernel_size: int = 3, dropout_rate: float = 0.5, loss=F.l1_loss, batch_norm=False, pool=False,
                  padding=1, dilation=1, groups=1, lr=1e-3, activation=nn.SiLU) -> None:
         super().__init__()
-        if batch_norm or pool or groups != 1:
-            raise NotImplementedError("batch_norm / pool / groups != 1 are not on the accelerated path yet")
         if activation not in ACT_CODES:
             raise ValueError(f"activation {activation} has no HIP implementation")
         self._act_code = ACT_CODES[activation]
-        self._padding, self._dilation = padding, dilation
+        self._padding, self._dilation, self._groups = padding, dilation, groups
         self.conv_layers = nn.Sequential()
         cur, width = channels, input_size
         for i, size in enumerate(layer_sizes):
@@ -50,6 +83,11 @@ class CNN(nn.Module):
                 f"conv{i+1}", nn.Conv1d(cur, size, kernel_size, padding=padding, dilation=dilation, groups=groups))
             self.conv_layers.add_module(f"act{i+1}", activation())
             width = width + 2 * padding - dilation * (kernel_size - 1)
+            if batch_norm:
+                self.conv_layers.add_module(f"bn{i+1}", nn.BatchNorm1d(size))
+            if pool:
+                self.conv_layers.add_module(f"pool{i+1}", nn.MaxPool1d(kernel_size=2, stride=2))
+                width //= 2
             cur = size
         self.dropout = nn.Dropout(dropout_rate)
         self.fc = nn.Linear(cur * width, output_size)
@@ -61,11 +99,7 @@ class CNN(nn.Module):
         dev = x.device if x.is_cuda else torch.device("cuda", 0)
         _lib.require_gpu(dev.index or 0)
         to = lambda t: t.detach().to(dev, torch.float32).contiguous()
-        h = to(x)
-        for m in self.conv_layers:
-            if isinstance(m, nn.Conv1d):
-                h = conv1d_forward(h, to(m.weight), to(m.bias) if m.bias is not None else None,
-                                   self._padding, self._dilation, self._act_code)
+        h = _run_conv_stack(self.conv_layers, to(x), to, self._padding, self._dilation, self._act_code, self._groups)
         h = h.reshape(h.shape[0], -1)
         h = dense_forward(h, to(self.fc.weight), to(self.fc.bias), None, None, 0)
         return h if x.is_cuda else h.cpu()
@@ -82,8 +116,8 @@ def autocorr_softmax(feat):
 
 
 class CCCNN(nn.Module):
-    """``model.CCCNN`` (model.py:443-538), non-grouped form: a shared single-input-channel conv
-    stack applied to every sensor channel, the auto-correlation of every feature map summed
+    """``model.CCCNN`` (model.py:443-538): a conv stack applied to every sensor channel (shared, or one
+    private stack per channel with ``group=True``), optional MaxPool, the auto-correlation of every feature map summed
     over the maps, a softmax over the lags, and a Linear on the flattened result.  Same
     constructor arguments and parameter names (``conv_layers.conv{i}``, ``fc``) as the
     reference; ``forward`` is inference-only and runs as HIP kernels."""
@@ -96,19 +130,24 @@ class CCCNN(nn.Module):
             kernel_sizes = [kernel_sizes] * len(layer_sizes)
         if isinstance(strides, int):
             strides = [strides] * len(layer_sizes)
-        if group or batch_norm or pool or any(s != 1 for s in strides):
-            raise NotImplementedError("group / batch_norm / pool / stride != 1 are not on the accelerated path yet")
+        if batch_norm or any(s != 1 for s in strides):
+            raise NotImplementedError("batch_norm (GroupNorm) / stride != 1 are not on the accelerated path yet")
         if activation not in ACT_CODES:
             raise ValueError(f"activation {activation} has no HIP implementation")
         self.group, self.channels = group, channels
         self._act_code, self._padding, self._dilation = ACT_CODES[activation], padding, dilation
         self.conv_layers = nn.Sequential()
-        cur, width = 1, input_size
+        g = channels if group else 1  # model.py:466,484: one private stack per sensor channel when grouped
+        cur, width = g, input_size
         for i, (size, k) in enumerate(zip(layer_sizes, kernel_sizes)):
-            self.conv_layers.add_module(f"conv{i+1}", nn.Conv1d(cur, size, k, padding=padding, dilation=dilation))
+            self.conv_layers.add_module(
+                f"conv{i+1}", nn.Conv1d(cur, size * g, k, padding=padding, dilation=dilation, groups=g))
             self.conv_layers.add_module(f"act{i+1}", activation())
             width = width + 2 * padding - dilation * (k - 1)
-            cur = size
+            if pool:
+                self.conv_layers.add_module(f"pool{i+1}", nn.MaxPool1d(kernel_size=2, stride=2))
+                width //= 2
+            cur = size * g
         self.dropout = nn.Dropout(dropout_rate)
         self.fc = nn.Linear(channels * (2 * width - 1), output_size)
 
@@ -118,11 +157,12 @@ class CCCNN(nn.Module):
         _lib.require_gpu(dev.index or 0)
         to = lambda t: t.detach().to(dev, torch.float32).contiguous()
         B, C, W = x.shape
-        h = to(x).reshape(B * C, 1, W)  # the shared stack sees every sensor channel as its own item
-        for m in self.conv_layers:
-            if isinstance(m, nn.Conv1d):
-                h = conv1d_forward(h, to(m.weight), to(m.bias) if m.bias is not None else None,
-                                   self._padding, self._dilation, self._act_code)
+        if self.group:  # grouped conv: [B, C*K, V], channel-major, i.e. already [B*C, K, V]
+            h = _run_conv_stack(self.conv_layers, to(x), to, self._padding, self._dilation, self._act_code, C)
+            h = h.reshape(B * C, h.shape[1] // C, h.shape[2])
+        else:  # the shared stack sees every sensor channel as its own item
+            h = _run_conv_stack(self.conv_layers, to(x).reshape(B * C, 1, W), to, self._padding, self._dilation,
+                                self._act_code, 1)
         probs = autocorr_softmax(h)  # [B*C, 2V-1]
         out = dense_forward(probs.reshape(B, -1), to(self.fc.weight), to(self.fc.bias), None, None, 0)
         return out if x.is_cuda else out.cpu()

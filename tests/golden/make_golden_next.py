@@ -5,6 +5,7 @@ Run in the build container only:   python tests/golden/make_golden_next.py
   g5_groups   detection.find_onset_groups   (detection.py:131-189)
   g12_xcorr   detection.cross_correlation_lag (detection.py:195-268)
   g13_fix     detection.fix_onsets / adjust_onset (detection.py:299-352, 373-451)
+  g14_model_variants  model.CNN / model.CCCNN with batch_norm / pool / groups / group
 Only inputs and the reference's outputs are stored.
 """
 import sys
@@ -136,7 +137,33 @@ def g13():
     save("g13_fix", **out)
 
 
+from make_golden_next_cfg import G14  # noqa: E402
+
+
+def g14():
+    """model.CNN / model.CCCNN with the constructor options of model.py:62-67, 451-456."""
+    import torch
+    torch.manual_seed(14)
+    out = {}
+    for name, (cls, kw) in G14.items():
+        m = getattr(ref.model, cls)(**kw)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 2.0)
+                mod.weight.data.uniform_(0.5, 1.5)
+                mod.bias.data.normal_(0, 0.2)
+        m.eval()
+        x = torch.randn(5, kw["channels"], kw["input_size"])
+        with torch.no_grad():
+            y = m(x)
+        for k, v in m.state_dict().items():
+            out[f"{name}/{k}"] = v.numpy()
+        out[f"{name}/x"], out[f"{name}/y"] = x.numpy(), y.numpy()
+    save("g14_model_variants", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g5", "g12", "g13"]
+    which = sys.argv[1:] or ["g5", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -67,3 +67,19 @@ def test_cnn_matches_reference_golden():
         m.load_state_dict(sd)
         y = m(torch.from_numpy(g[f"{name}/x"])).numpy()
         assert rel_err(y, g[f"{name}/y"]) < 1e-4, name
+
+
+def test_cnn_cccnn_constructor_options_match_reference_golden():
+    """batch_norm (eval), MaxPool, groups, dilation for CNN; group / pool for CCCNN (model.py:62-67, 451-456)."""
+    from onset_fingerprinting_amd import model
+    from tests.golden.make_golden_next_cfg import G14
+    g = load_golden("g14_model_variants")
+    for name, (cls, kw) in G14.items():
+        m = getattr(model, cls)(**kw).eval()
+        sd = {k.split("/", 1)[1]: torch.from_numpy(g[k]) for k in g.files
+              if k.startswith(name + "/") and k.split("/")[1] not in ("x", "y")}
+        m.load_state_dict(sd)  # the reference's own keys, BatchNorm buffers included
+        y = m(torch.from_numpy(g[f"{name}/x"])).numpy()
+        assert y.shape == g[f"{name}/y"].shape and rel_err(y, g[f"{name}/y"]) < 1e-4, name
+    with pytest.raises(NotImplementedError):
+        model.CCCNN(64, 2, batch_norm=True)
