@@ -52,7 +52,7 @@ TRAFFIC_BYTES_PER_LAUNCH = {}
 try:  # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), see profiles/README.md
     _t = json.load(open(REPO / "profiles" / "r01" / "v8_pmc_traffic_per_kernel.json"))
     TRAFFIC_BYTES_PER_LAUNCH = {"hp": _t["k_hp_candidates"]["hbm_mb_per_launch"] * 1e6,
-                                "stft": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
+                                "stft_mel": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
 except Exception:
     pass
 
@@ -121,12 +121,14 @@ def main():
         t_in = time.perf_counter()
         with torch.cuda.stream(streams[w]):
             out = pipes[w].run(xd, timed=timed)
+            # this rank's onset records, compacted into a tensor of their own (the pipeline's
+            # buffers are free for its next step as soon as this thread returns)
+            flat = flatten_records(out["records"], out["counts"], out["cap"], clip_offset=rank)
         streams[w].synchronize()
-        return out, time.perf_counter() - t_in
+        return out, flat, time.perf_counter() - t_in
 
-    def finish(out, lat, timed):
-        flat = flatten_records(out["records"], out["counts"], out["cap"], clip_offset=rank)
-        gathered = all_gather_onsets(flat)
+    def finish(out, flat, lat, timed):
+        gathered = all_gather_onsets(flat)  # the collective, in step order on this thread
         if timed:
             st = dict(out["info"]["stage_ms"])
             st.pop("total")
@@ -140,15 +142,12 @@ def main():
     workers = [ThreadPoolExecutor(1) for _ in range(D)]  # worker w runs steps w, w+D, ... in order
 
     def run_steps(n, timed):
-        # at most D steps outstanding; pipeline w gets its next step only after this thread has
-        # consumed (flattened, gathered) the outputs of its previous one
-        futs = {i: workers[i % D].submit(run_step, i % D, timed) for i in range(min(D, n))}
+        # D steps in flight: worker w runs steps w, w+D, ... one after the other
+        futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n)]
         res = None
-        for i in range(n):  # complete in step order; the collective runs on this thread
-            out, lat = futs.pop(i).result()
-            res = finish(out, lat, timed)
-            if i + D < n:
-                futs[i + D] = workers[i % D].submit(run_step, i % D, timed)
+        for f in futs:  # complete in step order
+            out, flat, lat = f.result()
+            res = finish(out, flat, lat, timed)
         return res
 
     def barrier():
@@ -169,11 +168,27 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * frames_per_rank / (ms_per_step / 1e3)
 
+    # the same steps strictly one after the other (outside the timed region above), so that the
+    # line also says what a single step costs when nothing else is in flight
+    single_ms = ms_per_step
+    if D > 1:
+        w1, n1 = args.steps % D, max(1, min(args.steps, 10))  # not the pipeline holding the last timed result
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            _, flat1, _ = run_step(w1, False)
+            all_gather_onsets(flat1)
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t1) / n1 * 1e3], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        single_ms = float(t.item())
+
     if rank == 0:
         out, power, mel, logits, gathered = res
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         stage_bytes = dict(hp=BYTES_DETECT, db=BYTES_DETECT, ar=BYTES_DETECT, rel=BYTES_DETECT, mm=BYTES_DETECT // 2,
-                           logic=BYTES_DETECT // 2, stft=BYTES_STFT, mel=BYTES_MEL, mlp=BYTES_MLP)
+                           logic=BYTES_DETECT // 2, stft_mel=BYTES_STFT + 4 * NMELS, mlp=BYTES_MLP)
         cand_ms = stage_ms.pop("hp_candidates", 0.0)  # a part of the hp stage, reported separately
         dom = max(stage_ms, key=stage_ms.get)
         passes = out["info"]
@@ -196,11 +211,13 @@ def main():
                                    "detect + rFFT |X|^2 + 40-mel + FCNN(40-10-10-10-8); RCCL all-gather of onsets",
                        "frames_per_gpu": frames_per_rank, "onsets_gathered": int(gathered.shape[0]),
                        "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D,
-                       "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3)},
+                       "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
+                       "one_step_at_a_time": {"ms_per_step": round(single_ms, 3),
+                                              "frames_per_s": round(world * frames_per_rank / (single_ms / 1e3))}},
             "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_coarse+k_ar_warm+k_ar_chunk",
                                                     "mm": "k_mm_max+k_mm_warm+k_mm_chunk", "db": "k_rect_db",
                                                     "rel": "k_rel_out", "logic": "k_block_scan+k_state_machine",
-                                                    "stft": "k_stft_power<1024>", "mel": "k_mel", "mlp": "k_dense"}[dom],
+                                                    "stft_mel": "k_stft_power<1024> (mel fused)", "mlp": "k_dense"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "launches_per_step": launches,
                          "avg_launch_ms": dom_ms / launches,

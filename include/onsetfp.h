@@ -188,6 +188,13 @@ int ofp_stream_process(ofp_detector* det, void* d_state, const float* d_x, int64
  *   output below is wanted. */
 int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels,
                    int32_t n_fft, int32_t hop, float* d_power, void* stream);
+/* The same with the mel filterbank of ofp_mel applied while a frame's power spectrum is still on
+ * chip: d_mel [n_clips][C][H][n_mels] (same values as ofp_mel on d_power); d_power may be NULL
+ * when only the mel fingerprint is wanted.  fb_nnz = number of weights in d_fb_w. */
+int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels, int32_t n_fft,
+                       int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
+                       const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
+                       float* d_mel, void* stream);
 
 /* Gathered complex STFT frames (data.py:593-654 semantics are built on this by
  * the Python layer): for each of n_frames (clip, channel, start) triples,

@@ -166,10 +166,20 @@ __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, i
 }
 
 // ---- dense power spectra --------------------------------------------------
+// Mel filterbank applied in the epilogue of k_stft_power (band-CSR as for ofp_mel): the power
+// spectrum of a frame is still in LDS when its n_mels band sums are taken, so the mel output costs
+// no second pass over the 2 KB-per-frame power array.
+struct MelFuse {
+    const int32_t *lo, *len, *off;
+    const float* w;
+    int n_mels, nnz;
+    float* mel;  // [total_frames][n_mels]; NULL: no mel output
+};
+
 template <int F>
 __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
-                                                            float* __restrict__ power) {
+                                                            float* __restrict__ power, MelFuse mf) {
     using G = Cfg<F>;
     constexpr int M = G::M, T = G::T, FPW = G::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -177,6 +187,20 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     float2* twF = twM + M;
     float* win = reinterpret_cast<float*>(twF + M + 2);
     float2* bufs = reinterpret_cast<float2*>(win + F);
+    // mel epilogue: power of the workgroup's frames [FPW][M+2], then the filterbank
+    float* pw = reinterpret_cast<float*>(bufs + (size_t)FPW * 2 * M);
+    float* fw = pw + (size_t)FPW * (M + 2);
+    int32_t* flo = reinterpret_cast<int32_t*>(fw + mf.nnz);
+    int32_t* flen = flo + mf.n_mels;
+    int32_t* foff = flen + mf.n_mels;
+    if (mf.mel) {
+        for (int i = threadIdx.x; i < mf.nnz; i += blockDim.x) fw[i] = mf.w[i];
+        for (int i = threadIdx.x; i < mf.n_mels; i += blockDim.x) {
+            flo[i] = mf.lo[i];
+            flen[i] = mf.len[i];
+            foff[i] = mf.off[i];
+        }
+    }
     build_tables<F>(twM, twF, win, F);
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
@@ -201,10 +225,26 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         }
         float2* Z = cfft<M, T>(A, Bf, twM, tid);
         if (valid) {
-            float* dst = power + f * (M + 1);
+            float* dst = power ? power + f * (M + 1) : nullptr;
+            float* pf = pw + (size_t)sub * (M + 2);
             for (int k = tid; k <= M; k += T) {
                 float2 X = rfft_bin<M>(Z, twF, k);
-                dst[k] = X.x * X.x + X.y * X.y;
+                const float p = X.x * X.x + X.y * X.y;
+                if (dst) dst[k] = p;
+                if (mf.mel) pf[k] = p;
+            }
+        }
+        if (mf.mel) {
+            __syncthreads();
+            if (valid) {
+                const float* pf = pw + (size_t)sub * (M + 2);
+                for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
+                    const float* p = pf + flo[b];
+                    const float* wb = fw + foff[b];
+                    float acc = 0.0f;
+                    for (int k = 0; k < flen[b]; ++k) acc = fmaf(p[k], wb[k], acc);
+                    mf.mel[f * mf.n_mels + b] = acc;
+                }
             }
         }
     }
@@ -339,18 +379,20 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
 
 template <int F>
 int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
-                 hipStream_t stream) {
+                 const MelFuse& mf, hipStream_t stream) {
     using G = Cfg<F>;
-    static bool attr_set = false;
-    if (!attr_set && G::lds_bytes > 65536) {
+    size_t lds = G::lds_bytes;
+    if (mf.mel) lds += (size_t)G::FPW * (G::M + 2) * 4 + (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
+    static size_t attr_set = 0;
+    if (lds > 65536 && lds > attr_set) {
         OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
-        attr_set = true;
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
     }
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
-    hipLaunchKernelGGL(k_stft_power<F>, dim3(grid), dim3(G::WG), G::lds_bytes, stream, x, n_samples, C, hop, H,
-                       total, power);
+    hipLaunchKernelGGL(k_stft_power<F>, dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
+                       power, mf);
     OFP_LAUNCH_CHECK("k_stft_power");
     return OFP_OK;
 }
@@ -375,22 +417,39 @@ int launch_frames(const FrameArgs& a, hipStream_t stream) {
 
 extern "C" {
 
-int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
-                   int32_t hop, float* d_power, void* stream_) {
-    OFP_REQUIRE(d_x && d_power, "ofp_stft_power: NULL argument");
+static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
+                           int32_t hop, float* d_power, const MelFuse& mf, void* stream_) {
+    OFP_REQUIRE(d_x && (d_power || mf.mel), "ofp_stft_power: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && C >= 1 && hop >= 1, "ofp_stft_power: bad sizes");
     if (n_samples < n_fft) return OFP_OK;  // no complete frame
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t H = 1 + (n_samples - n_fft) / hop;
     const int64_t total = n_clips * C * H;
     switch (n_fft) {
-        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, stream);
-        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, stream);
-        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, stream);
-        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, stream);
-        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, stream);
+        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
+        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
+        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
+        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
+        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
         default: return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", n_fft);
     }
+}
+
+int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
+                   int32_t hop, float* d_power, void* stream) {
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, MelFuse{}, stream);
+}
+
+int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
+                       int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
+                       const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
+                       float* d_mel, void* stream) {
+    OFP_REQUIRE(d_fb_lo && d_fb_len && d_fb_off && d_fb_w && d_mel && n_mels >= 1 && fb_nnz >= 1,
+                "ofp_stft_power_mel: NULL / empty filterbank");
+    OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel: filterbank with %d weights for %d bins", fb_nnz,
+                n_fft / 2 + 1);
+    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel};
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, stream);
 }
 
 int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, const int32_t* d_clip,

@@ -89,6 +89,27 @@ def stft_power_dense(x, n_fft, hop, out=None):
     return out
 
 
+def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, want_power=True):
+    """`stft_power_dense` and `melbank(power)` in one kernel: the filterbank is applied while each
+    frame's power spectrum is still in LDS.  Returns (power or None, mel [n_clips, C, H, n_mels])."""
+    if n_fft not in SUPPORTED_NFFT:
+        raise ValueError(f"n_fft must be one of {SUPPORTED_NFFT}, got {n_fft}")
+    L = _lib.lib()
+    n_clips, N, C = x.shape
+    H = 0 if N < n_fft else 1 + (N - n_fft) // hop
+    if want_power and out_power is None:
+        out_power = torch.empty((n_clips, C, H, n_fft // 2 + 1), dtype=torch.float32, device=x.device)
+    if out_mel is None:
+        out_mel = torch.empty((n_clips, C, H, melbank.n_mels), dtype=torch.float32, device=x.device)
+    if H:
+        check(L.ofp_stft_power_mel(x.data_ptr(), n_clips, N, C, n_fft, hop,
+                                   out_power.data_ptr() if want_power else None, melbank.n_mels,
+                                   melbank.lo.data_ptr(), melbank.len.data_ptr(), melbank.off.data_ptr(),
+                                   melbank.w.data_ptr(), melbank.w.numel(), out_mel.data_ptr(), _stream(x.device)),
+              "ofp_stft_power_mel")
+    return (out_power if want_power else None), out_mel
+
+
 # ---- mel filterbank (librosa's published definition; PARITY UNPINNED, SURVEY 8c) --
 
 def _hz_to_mel(f):

@@ -136,3 +136,21 @@ def test_window_contribution_weights(data):
     w = oracle.hann_periodic(1024)
     np.testing.assert_allclose(data.window_contribution_weights(w, 256), g["w1024_256"], rtol=1e-12)
     np.testing.assert_allclose(data.window_contribution_weights(w, 256, True), g["w1024_256_hep"], rtol=1e-12)
+
+
+def test_fused_stft_mel_equals_the_two_kernels():
+    """ofp_stft_power_mel == ofp_stft_power followed by ofp_mel, bit for bit (same summation
+    order), for every supported n_fft, ragged frame counts, and with the power output dropped."""
+    import torch
+    from onset_fingerprinting_amd import data
+    rng = np.random.default_rng(77)
+    for n_fft, hop, C, N in ((256, 64, 3, 5000), (512, 128, 2, 7777), (1024, 256, 8, 40000), (2048, 512, 2, 30011),
+                             (4096, 1024, 1, 20000)):
+        x = torch.from_numpy(rng.standard_normal((2, N, C)).astype(np.float32)).cuda()
+        mb = data.MelBank(48000, n_fft, 40)
+        p0 = data.stft_power_dense(x, n_fft, hop)
+        m0 = mb(p0)
+        p1, m1 = data.stft_power_mel_dense(x, n_fft, hop, mb)
+        assert torch.equal(p0, p1) and torch.equal(m0, m1), n_fft
+        p2, m2 = data.stft_power_mel_dense(x, n_fft, hop, mb, want_power=False)
+        assert p2 is None and torch.equal(m0, m2)
