@@ -134,3 +134,43 @@ def test_c5_streaming_per_hop_in_a_hip_graph(mods):
     assert n == len(exp_c) and n > 5
     assert [int(v) for v in got["channel"]] == exp_c and [int(v) for v in got["sample"]] == exp_d
     assert np.array_equal(bits(torch.stack(rels).cpu().numpy().reshape(-1, C)), bits(np.concatenate(exp_rel)))
+
+
+def test_pipelines_in_flight_from_several_threads_give_the_same_bytes():
+    """bench.py keeps several steps in flight, each pipeline instance driven by its own host thread on
+    its own streams: the library must be re-entrant per handle.  Three different clips, processed
+    concurrently several times over, must reproduce what each gives alone, byte for byte."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from onset_fingerprinting_amd import synth
+    from onset_fingerprinting_amd.pipeline import FingerprintPipeline
+    C, sr = 4, 48000
+    clips = [torch.from_numpy(synth.drum_hits(C, 6.0, sr, seed=50 + i, period=0.21 + 0.04 * i)).cuda().unsqueeze(0)
+             for i in range(3)]
+    pipes = [FingerprintPipeline(C, 1024, 256, sr, 40) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+
+    def snapshot(out):
+        n = int(out["counts"][0])
+        return (out["records"][0, :n].cpu().numpy().copy(), out["rel"].cpu().numpy().copy(),
+                out["mel"].cpu().numpy().copy(), out["logits"].cpu().numpy().copy())
+
+    alone = [snapshot(pipes[i].run(clips[i])) for i in range(3)]
+
+    def work(i):
+        torch.cuda.set_device(0)
+        res = []
+        with torch.cuda.stream(streams[i]):
+            for _ in range(4):
+                out = pipes[i].run(clips[i])
+                streams[i].synchronize()
+                res.append(snapshot(out))
+        return res
+
+    with ThreadPoolExecutor(3) as ex:
+        results = list(ex.map(work, range(3)))
+    for i in range(3):
+        assert len(alone[i][0]) > 10
+        for got in results[i]:
+            for a, b in zip(alone[i], got):
+                assert a.shape == b.shape and a.tobytes() == b.tobytes()
