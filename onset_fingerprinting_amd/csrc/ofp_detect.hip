@@ -447,6 +447,8 @@ struct MmArgs {
     float* thr_mx;
     float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
     int64_t nb, L, W, n_chunks;
+    uint8_t* dirty;  // [chains][n_chunks] chunk must be run again although its start matches (k_mm_sweep)
+    int64_t n_chains;
 };
 
 // lean kernels, as for the followers:
@@ -524,11 +526,13 @@ __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_t
             return;
         }
         const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
-        if (p0 == i0 && p1 == i1) {
+        const bool redo = a.dirty[id] != 0;  // k_mm_sweep changed this chunk's start after pass 0
+        if (p0 == i0 && p1 == i1 && !redo) {
             end_next[sidx] = end_prev[sidx];
             end_next[sidx + 1] = end_prev[sidx + 1];
             return;
         }
+        a.dirty[id] = 0;
         i0 = p0;
         i1 = p1;
         used[sidx] = i0;
@@ -563,6 +567,37 @@ __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_t
     walk<8, 0, true>(a.rel + chain * a.g.U + start, nullptr, end - start, rem, s);
     end_next[sidx] = ofp_f2u(s.mn);
     end_next[sidx + 1] = ofp_f2u(s.mx);
+}
+
+// The max coalesces only where the true max is reset, so a stretch without a reset (a loud hit
+// followed by seconds of quieter ones) leaves every chunk start inside it wrong after the
+// speculative warm-up, and the repair then advances ONE chunk per pass.  The max recurrence does
+// not involve the min, so once a pass has found something to repair the host switches to LIGHT
+// passes: the same verify-and-repair rule applied to the max alone (11 ns per step instead of the
+// full step, eight passes per host round trip), which marks the chunks it corrects dirty; the full
+// passes that follow run those again and remain the verification.
+__global__ __launch_bounds__(64) void k_mm_maxpass(MmArgs a, int64_t n_threads, const uint32_t* __restrict__ end_prev,
+                                                   uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                   int* changed) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    end_next[sidx] = end_prev[sidx];  // the min is not touched here
+    if (k == 0 || used[sidx + 1] == end_prev[sidx - 1]) {
+        end_next[sidx + 1] = end_prev[sidx + 1];
+        return;
+    }
+    const uint32_t t = end_prev[sidx - 1];
+    used[sidx + 1] = t;
+    MaxStep mo{ofp_u2f(t), a.ialpha_max, a.alpha_max};
+    int norem = -1;
+    const int64_t start = k * a.L;
+    walk<16, 0, false>(a.rel + chain * a.g.U + start, nullptr, min(start + a.L, a.g.U) - start, norem, mo);
+    end_next[sidx + 1] = ofp_f2u(mo.mx);
+    a.dirty[id] = 1;
+    atomicAdd(changed, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1318,7 +1353,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_pos, o_ar_state, o_ar_P, o_mm_state,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, total;
 };
 
@@ -1410,6 +1445,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
     l.o_ar_P = take(n_clips * l.ar_chunks * g.C * 8);
     l.o_mm_state = take(3 * n_clips * l.mm_chunks * g.C * 2 * 4);
+    l.o_mm_dirty = take(n_clips * l.mm_chunks * g.C);
     l.o_thr_mn = take(n_clips * l.nb * g.C * 4);
     l.o_thr_mx = take(n_clips * l.nb * g.C * 4);
     l.o_first = take(n_clips * l.nb * g.C * 4);
@@ -1428,7 +1464,8 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
 // until a pass changes nothing.  used[] has been filled by the stage's warm-up kernels.
 template <class K, class A>
 int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
-               int* d_changed, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired) {
+               int* d_changed, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired,
+               void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, hipStream_t) = nullptr) {
     const int64_t words = n_threads * 2;
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
@@ -1454,6 +1491,20 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
         if (changed == 0) break;
         if (max_passes > 0 && pass >= max_passes)
             return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name, changed, pass);
+        if (light_pass) {  // a cascade is under way: light passes, eight per host round trip
+            for (int group = 0; group < 4096; ++group) {
+                OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+                for (int q = 0; q < 8; ++q) {
+                    light_pass(args, n_threads, prev, next, used, d_changed, stream);
+                    std::swap(prev, next);
+                }
+                OFP_LAUNCH_CHECK(name);
+                OFP_HIP(hipMemcpyAsync(h_flags, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+                OFP_HIP(hipStreamSynchronize(stream));
+                *repaired += h_flags[0];
+                if (h_flags[0] == 0) break;
+            }
+        }
     }
     return OFP_OK;
 }
@@ -1710,15 +1761,23 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.L = l.mm_L;
         a.W = l.mm_W;
         a.n_chunks = l.mm_chunks;
+        a.n_chains = chains;
+        a.dirty = reinterpret_cast<uint8_t*>(ws + l.o_mm_dirty);
         const int64_t nt = chains * l.mm_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
+        OFP_HIP(hipMemsetAsync(a.dirty, 0, nt, stream));
         hipLaunchKernelGGL(k_mm_max, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_mm_max");
         hipLaunchKernelGGL(k_mm_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_mm_warm");
         int rc = run_jacobi("tracker stage", k_mm_chunk, a, nt, l.mm_chunks, used, d_changed, d->h_flags, d->t.max_passes, stream,
-                            &info[2], &info[3]);
+                            &info[2], &info[3],
+                            +[](const MmArgs& m, int64_t n, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch,
+                                hipStream_t st) {
+                                hipLaunchKernelGGL(k_mm_maxpass, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en,
+                                                   u, ch);
+                            });
         if (rc != OFP_OK) return rc;
     }
     OFP_HIP(hipEventRecord(ev[5], stream));

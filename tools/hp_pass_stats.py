@@ -25,7 +25,7 @@ for cfg in configs:
     bd = detection.BatchDetector(8, 256, sr=sr)
     if cfg:
         bd.set_tuning(**cfg)
-    passes, rep, ms = [], [], []
+    passes, rep, ms, mmp, mmms = [], [], [], [], []
     for x in inputs:
         xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
         out = bd.detect(xd, want_rel=False)
@@ -34,4 +34,6 @@ for cfg in configs:
         passes.append(i["hp_passes"])
         rep.append(i["repaired"])
         ms.append(round(i["stage_ms"]["hp"], 2))
-    print(cfg, "hp rounds", passes, "mean %.2f" % np.mean(passes), "hp ms", ms, "mean %.2f" % np.mean(ms), flush=True)
+        mmp.append(i["mm_passes"])
+        mmms.append(round(i["stage_ms"]["mm"], 2))
+    print(cfg, "hp rounds", passes, "mean %.2f" % np.mean(passes), "hp ms", ms, "mean %.2f" % np.mean(ms), "| mm passes", mmp, "mm ms", mmms, "mean %.2f" % np.mean(mmms), flush=True)
