@@ -1582,6 +1582,12 @@ int ofp_detector_set_tuning(ofp_detector* d, const ofp_detect_tuning* t) {
     return OFP_OK;
 }
 
+const float* ofp_detect_planar_input(const ofp_detector* d, int64_t n_clips, int64_t n_samples, int64_t warm,
+                                     const void* d_ws) {
+    if (!d || !d_ws || n_clips < 1 || n_samples < 0) return nullptr;
+    return reinterpret_cast<const float*>(static_cast<const char*>(d_ws) + make_layout(d, n_clips, n_samples, warm).o_xt);
+}
+
 int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64_t n_samples,
                                    int64_t warm) {
     if (!d || n_clips < 0 || n_samples < 0) return -1;

@@ -179,7 +179,7 @@ struct MelFuse {
 template <int F>
 __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
-                                                            float* __restrict__ power, MelFuse mf) {
+                                                            float* __restrict__ power, MelFuse mf, int planar) {
     using G = Cfg<F>;
     constexpr int M = G::M, T = G::T, FPW = G::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -216,10 +216,14 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             const int64_t cc = f / H;  // clip*C + c
             const int c = (int)(cc % C);
             const int64_t clip = cc / C;
-            const float* src = x + (clip * n_samples + h * hop) * C + c;
+            // interleaved [clip][time][C] (the caller's layout: a lane's two samples sit in two 32-B
+            // sectors of which it uses 4 B) or planar [clip][C][time] (consecutive lanes, consecutive
+            // floats: the detector's transposed copy, 8x less L2 traffic at C = 8)
+            const int64_t stride = planar ? 1 : C;
+            const float* src = planar ? x + cc * n_samples + h * hop : x + (clip * n_samples + h * hop) * C + c;
             for (int n = tid; n < M; n += T) {
-                float a = src[(int64_t)(2 * n) * C] * win[2 * n];
-                float b = src[(int64_t)(2 * n + 1) * C] * win[2 * n + 1];
+                float a = src[(int64_t)(2 * n) * stride] * win[2 * n];
+                float b = src[(int64_t)(2 * n + 1) * stride] * win[2 * n + 1];
                 A[n] = make_float2(a, b);
             }
         }
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
                     const float* p = pf + flo[b];
                     const float* wb = fw + foff[b];
                     float acc = 0.0f;
-                    for (int k = 0; k < flen[b]; ++k) acc = fmaf(p[k], wb[k], acc);
+                    const int nb_ = flen[b];
+#pragma unroll 4
+                    for (int k = 0; k < nb_; ++k) acc = fmaf(p[k], wb[k], acc);
                     mf.mel[f * mf.n_mels + b] = acc;
                 }
             }
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
 
 template <int F>
 int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
-                 const MelFuse& mf, hipStream_t stream) {
+                 const MelFuse& mf, int planar, hipStream_t stream) {
     using G = Cfg<F>;
     size_t lds = G::lds_bytes;
     if (mf.mel) lds += (size_t)G::FPW * (G::M + 2) * 4 + (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
@@ -392,7 +398,7 @@ int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, i
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
     hipLaunchKernelGGL(k_stft_power<F>, dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
-                       power, mf);
+                       power, mf, planar);
     OFP_LAUNCH_CHECK("k_stft_power");
     return OFP_OK;
 }
@@ -418,7 +424,7 @@ int launch_frames(const FrameArgs& a, hipStream_t stream) {
 extern "C" {
 
 static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
-                           int32_t hop, float* d_power, const MelFuse& mf, void* stream_) {
+                           int32_t hop, float* d_power, const MelFuse& mf, int planar, void* stream_) {
     OFP_REQUIRE(d_x && (d_power || mf.mel), "ofp_stft_power: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && C >= 1 && hop >= 1, "ofp_stft_power: bad sizes");
     if (n_samples < n_fft) return OFP_OK;  // no complete frame
@@ -426,30 +432,30 @@ static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples,
     const int64_t H = 1 + (n_samples - n_fft) / hop;
     const int64_t total = n_clips * C * H;
     switch (n_fft) {
-        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
-        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
-        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
-        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
-        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, mf, stream);
+        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
+        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
+        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
+        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
+        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
         default: return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", n_fft);
     }
 }
 
 int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
                    int32_t hop, float* d_power, void* stream) {
-    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, MelFuse{}, stream);
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, MelFuse{}, 0, stream);
 }
 
 int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
                        int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
                        const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
-                       float* d_mel, void* stream) {
+                       float* d_mel, int32_t planar_input, void* stream) {
     OFP_REQUIRE(d_fb_lo && d_fb_len && d_fb_off && d_fb_w && d_mel && n_mels >= 1 && fb_nnz >= 1,
                 "ofp_stft_power_mel: NULL / empty filterbank");
     OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel: filterbank with %d weights for %d bins", fb_nnz,
                 n_fft / 2 + 1);
     MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel};
-    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, stream);
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_input ? 1 : 0, stream);
 }
 
 int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, const int32_t* d_clip,

@@ -139,6 +139,16 @@ class BatchDetector:
         check(self.d.lib.ofp_detect_offline_begin(self.d.handle, x.data_ptr(), n_clips, N, warm, ws.data_ptr(),
                                                   ws.numel(), _stream_ptr(x.device)), "ofp_detect_offline_begin")
 
+    def planar_input(self, x, warm=None):
+        """Device address of the transposed copy [n_clips][C][N] of `x` that `begin` (or `detect`)
+        left in the work space; valid until the next begin/detect on this detector."""
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        n_clips, N, C = x.shape
+        warm = int(0.5 * self.sr) if warm is None else int(warm)
+        ws = self.reserve(n_clips, N, warm)
+        return self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr())
+
     def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
         """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of
         device tensors: ``records`` (uint8 view of ofp_onset [n_clips, cap]),

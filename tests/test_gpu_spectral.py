@@ -154,3 +154,6 @@ def test_fused_stft_mel_equals_the_two_kernels():
         assert torch.equal(p0, p1) and torch.equal(m0, m1), n_fft
         p2, m2 = data.stft_power_mel_dense(x, n_fft, hop, mb, want_power=False)
         assert p2 is None and torch.equal(m0, m2)
+        xt = x.transpose(1, 2).contiguous()  # planar [clip][C][N]: same values, coalesced loads
+        p3, m3 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar_ptr=xt.data_ptr())
+        assert torch.equal(p0, p3) and torch.equal(m0, m3)
