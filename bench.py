@@ -6,7 +6,7 @@
 One step = one pass of detect -> rFFT |X|^2 -> 40-mel -> FCNN over one batch of
 synthetic audio already resident in HBM, plus (N > 1) the RCCL all-gather that
 collates onset records.  The detector is a chain of latency-bound recurrences that
-fills a fraction of the chip, so `--inflight` steps (default 4) are in flight at a
+fills a fraction of the chip, so `--inflight` steps (default 6) are in flight at a
 time on each GPU, each on its own pipeline instance (work space, buffers, streams,
 host thread); every step is still one complete pass over one clip, steps complete and
 are gathered in order, and `config.latency_ms_per_step` reports what one step takes
@@ -79,11 +79,11 @@ def cpu_baseline(x, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=4, help="steps (clips) processed concurrently per GPU")
+    ap.add_argument("--inflight", type=int, default=6, help="steps (clips) processed concurrently per GPU")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
     args = ap.parse_args()
 

@@ -115,6 +115,9 @@ typedef struct ofp_detect_tuning {
     int64_t ar_guess;            /* follower stage, how the exact warm-up gets its starting guess:
                                     0 auto, 1 sequential approximate pass, 2 closed-form dot product
                                     (needs slow attack == slow release; auto picks it when they are) */
+    int64_t hp_span;             /* IIR stage: 1 (default), 2 or 4 = chunks one speculative run walks through
+                                    after its warm-up; > 1 shares the warm-up between chunks: less work,
+                                    fewer waves, longer launch (throughput instead of latency) */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -53,6 +53,7 @@ class DetectTuning(ctypes.Structure):
         ("hp_candidates", ctypes.c_int64),
         ("hp_candidate_offset", ctypes.c_int64),
         ("ar_guess", ctypes.c_int64),
+        ("hp_span", ctypes.c_int64),
     ]
 
 

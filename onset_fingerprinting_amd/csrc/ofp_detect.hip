@@ -637,6 +637,7 @@ struct HpCand {
     HpArgs st;
     int R;            // candidates per chunk (slots 0..R-1; slot R = exact re-run)
     int64_t delta;    // offset between candidate starts
+    int span;         // chunks one run walks through (R % span == 0)
     uint32_t* U;      // [clips][chunks][C][R+1][4]
     uint32_t* E;      // same shape
     int8_t* sel;      // [clips][chunks][C] chosen slot, -1 unknown
@@ -677,26 +678,35 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
-    // candidate fastest: the R candidates of one chunk read the same window (shifted by
-    // r*delta), so neighbouring lanes share cache lines instead of each lane streaming its own
-    // 200 KB through the L2 (16x less fabric traffic at R = 16)
+    // One lane = one RUN: it warms up over W samples before chunk j and then walks through `span`
+    // consecutive chunks, leaving a candidate at every boundary it passes (slot i*Rm + r for chunk
+    // j + i).  span = 1: every candidate has its own warm-up (shortest kernel).  span = 4: the 16
+    // candidates of a chunk come from 4 runs started at each of the 4 preceding boundaries, the
+    // warm-up is shared by 4 chunks and the launch does 2.7x less work in a quarter of the waves,
+    // at the price of 3 more chunks of latency -- the throughput setting when several steps are
+    // in flight.  Lane order: the Rm runs of one boundary are neighbours (they read the same
+    // window shifted by r*delta and share cache lines).
+    const int Rm = a.R / a.span;
     int64_t q = id;
-    const int r = (int)(q % a.R);
-    q /= a.R;
-    const int64_t k = q % st.n_chunks;
+    const int r = (int)(q % Rm);
+    q /= Rm;
+    const int64_t j = q % st.n_chunks;
     const int64_t chain = q / st.n_chunks;  // clip*C + c
     const int C = st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
-    const int64_t start = k * st.L;
-    const int64_t end = min(start + st.L, st.g.V);
-    const int64_t si = a.slot(clip, k, c, r);
     if (r == 0) {
-        a.sel[(clip * st.n_chunks + k) * C + c] = (k == 0) ? 0 : -1;
-        for (int sb = 0; sb < a.S; ++sb) a.done[((clip * st.n_chunks + k) * C + c) * a.S + sb] = 0;
-        a.guessed[(clip * st.n_chunks + k) * C + c] = 0;
-        a.ran[(clip * st.n_chunks + k) * C + c] = -2;
-        a.U[a.slot(clip, k, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
+        const int64_t ci = (clip * st.n_chunks + j) * C + c;
+        a.sel[ci] = (j == 0) ? 0 : -1;
+        for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+        a.guessed[ci] = 0;
+        a.ran[ci] = -2;
+        a.U[a.slot(clip, j, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
+        // slots of runs that would have started before the stream: never match, never agree
+        for (int rr = (int)min<int64_t>((j + 1) * Rm, a.R); rr < a.R; ++rr) {
+            a.U[a.slot(clip, j, c, rr)] = 0x7fc00001u;
+            a.E[a.slot(clip, j, c, rr)] = 0x7fc00100u + (uint32_t)rr;
+        }
     }
     HpStep s;
     s.coeffs(st.b, st.a);
@@ -707,19 +717,28 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
     // slightly different states (r/1024 in z[0]; the difference decays below an ulp within ~200
     // samples, the histories stay distinct).
     if (a.delta == 0) s.z[0] = (float)r * 0.0009765625f;
-    const int64_t ws = max<int64_t>(start - st.W - (int64_t)r * a.delta, 0);
-    hp_span<false>(st, s, chain, ws, start);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a.U[si + i] = ofp_f2u(s.z[i]);
+    const int64_t ws = max<int64_t>(j * st.L - st.W - (int64_t)r * a.delta, 0);
+    hp_span<false>(st, s, chain, ws, j * st.L);
     const int64_t Ls = st.L / a.S;
 #pragma unroll 1
-    for (int sb = 0; sb < a.S; ++sb) {
-        const int64_t t0 = min(start + sb * Ls, end);
-        const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
-        hp_span<false>(st, s, chain, t0, t1);
-        uint32_t* dst = sb == a.S - 1 ? a.E + si : a.M + a.mslot(clip, k, c, r, sb);
+    for (int i = 0; i < a.span; ++i) {
+        const int64_t k = j + i;
+        if (k >= st.n_chunks) break;
+        const int slot = i * Rm + r;
+        const int64_t start = k * st.L;
+        const int64_t end = min(start + st.L, st.g.V);
+        const int64_t si = a.slot(clip, k, c, slot);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = ofp_f2u(s.z[i]);
+        for (int w = 0; w < 4; ++w) a.U[si + w] = ofp_f2u(s.z[w]);
+#pragma unroll 1
+        for (int sb = 0; sb < a.S; ++sb) {
+            const int64_t t0 = min(start + sb * Ls, end);
+            const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
+            hp_span<false>(st, s, chain, t0, t1);
+            uint32_t* dst = sb == a.S - 1 ? a.E + si : a.M + a.mslot(clip, k, c, slot, sb);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dst[w] = ofp_f2u(s.z[w]);
+        }
     }
 }
 
@@ -1347,7 +1366,7 @@ struct Layout {
     Geom g;
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
-    int hp_R, hp_S;
+    int hp_R, hp_S, hp_span;
     int64_t ar_L, ar_W, ar_Wc, ar_chunks;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks;
@@ -1396,6 +1415,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // few verification rounds as with ~1000), yet the 16 lanes of a chunk read 4 cache lines per
     // load instead of 16 and no lane runs much longer than W + L.  < 0: common start, see kernel.
     l.hp_delta = d->t.hp_candidate_offset < 0 ? 0 : pick(d->t.hp_candidate_offset, 8);
+    l.hp_span = (d->t.hp_span == 2 || d->t.hp_span == 4) && l.hp_R % (int)d->t.hp_span == 0 ? (int)d->t.hp_span : 1;
     l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
     l.ar_L = pick(d->t.ar_chunk, arL);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
@@ -1653,6 +1673,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.st.n_chunks = l.hp_chunks;
         hc.R = l.hp_R;
         hc.delta = l.hp_delta;
+        hc.span = l.hp_span;
         hc.U = reinterpret_cast<uint32_t*>(ws + l.o_hp_U);
         hc.E = reinterpret_cast<uint32_t*>(ws + l.o_hp_E);
         hc.sel = reinterpret_cast<int8_t*>(ws + l.o_hp_sel);
@@ -1664,7 +1685,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.ran = reinterpret_cast<int8_t*>(ws + l.o_hp_ran);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
-        const int64_t nA = chains * l.hp_chunks * hc.R;
+        const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
         if (phase != 2) {
