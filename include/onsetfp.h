@@ -250,8 +250,12 @@ int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float*
  * d_y [n][cout][wout], wout = w + 2*padding - dilation*(k-1)   (model.py:84-95) */
 int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w /*[cout][cin/groups][k]*/,
                const float* d_b, int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t groups,
-               int32_t act, const float* d_bn_scale /*[cout] or NULL*/, const float* d_bn_shift,
+               int32_t stride, int32_t act, const float* d_bn_scale /*[cout] or NULL*/, const float* d_bn_shift,
                int32_t pool /* MaxPool1d(2, 2) after the affine */, float* d_y, void* stream);
+/* nn.GroupNorm(1, K) over items d_x [n][K][V] (CCCNN with batch_norm=True, model.py:497-501), then
+ * optionally MaxPool1d(2, 2): d_y [n][K][V or V/2]; d_gamma / d_beta [K] or NULL.  Not in place. */
+int ofp_groupnorm1(const float* d_x, int64_t n, int32_t K, int32_t V, const float* d_gamma, const float* d_beta,
+                   float eps, int32_t pool, float* d_y, void* stream);
 
 /* CCCNN correlation head (model.py:524-534): d_x [n][K][V] feature maps -> d_out [n][2V-1]:
  * full auto-correlation of every map, summed over the K maps, soft-maxed over the lags. */

@@ -97,8 +97,9 @@ SIGNATURES = {
     "ofp_mfcc": (ctypes.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "ofp_dense": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
-    "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32,
-                                  _vp, _vp]),
+    "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
+                                  _i32, _vp, _vp]),
+    "ofp_groupnorm1": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp]),
     "ofp_group_workspace_bytes": (_i64, [_i64, _i64]),
     "ofp_group_onsets": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _i64,
                                         _vp]),

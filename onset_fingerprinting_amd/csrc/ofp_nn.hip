@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ x, int6
     }
 }
 
-// Conv1d (stride 1, any groups) + bias + activation, then the optional per-channel affine of an
+// Conv1d (any stride, any groups) + bias + activation, then the optional per-channel affine of an
 // eval-mode BatchNorm1d and MaxPool1d(2, 2) -- the layer of model.py:91-107 in one pass.
 // Thread per output element (after pooling).
 __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int64_t n, int cin, int w,
                                                 const float* __restrict__ wt, const float* __restrict__ b,
-                                                int cout, int k, int padding, int dilation, int groups, int act,
-                                                const float* __restrict__ bn_scale,
+                                                int cout, int k, int padding, int dilation, int groups, int stride,
+                                                int act, const float* __restrict__ bn_scale,
                                                 const float* __restrict__ bn_shift, int pool, int wout,
                                                 float* __restrict__ y) {
     const int64_t total = n * cout * wout;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
         const float* ws = wt + (int64_t)o * cin_g * k;
         float best = 0.0f;
         for (int h = 0; h <= pool; ++h) {
-            const int pc = pool ? 2 * p + h : p;  // position in the un-pooled row
+            const int pc = (pool ? 2 * p + h : p) * stride;  // first tap, in input samples, before padding
             float acc = b ? b[o] : 0.0f;
             for (int ci = 0; ci < cin_g; ++ci) {
                 for (int kk = 0; kk < k; ++kk) {
@@ -98,6 +98,57 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
             best = h == 0 ? v : fmaxf(best, v);
         }
         y[i] = best;
+    }
+}
+
+// nn.GroupNorm(1, K) (what CCCNN's batch_norm=True builds, model.py:497-501): every item [K][V] is
+// normalised by the mean and (biased) variance of all its K*V values, then scaled and shifted per
+// channel.  One workgroup per item; sums in fp64.  Optional MaxPool1d(2, 2) on the way out.
+__global__ __launch_bounds__(256) void k_groupnorm1(const float* __restrict__ x, int K, int V,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float eps, int pool, float* __restrict__ y) {
+    __shared__ double red[2][4];
+    __shared__ float stat[2];
+    const int64_t item = blockIdx.x;
+    const float* src = x + item * (int64_t)K * V;
+    const int n = K * V;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double v = (double)src[i];
+        s += v;
+        ss += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ts = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const double tss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = ts / n;
+        const double var = fmax(tss / n - mean * mean, 0.0);
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const int Vo = pool ? V / 2 : V;
+    float* dst = y + item * (int64_t)K * Vo;
+    for (int i = threadIdx.x; i < K * Vo; i += 256) {
+        const int k = i / Vo, p = i - k * Vo;
+        const float g = gamma ? gamma[k] : 1.0f, b = beta ? beta[k] : 0.0f;
+        if (pool) {
+            const float a0 = (src[k * V + 2 * p] - mean) * rstd * g + b;
+            const float a1 = (src[k * V + 2 * p + 1] - mean) * rstd * g + b;
+            dst[i] = fmaxf(a0, a1);
+        } else {
+            dst[i] = (src[k * V + p] - mean) * rstd * g + b;
+        }
     }
 }
 
@@ -181,23 +232,37 @@ int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float*
 }
 
 int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w, const float* d_b,
-               int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t groups, int32_t act,
-               const float* d_bn_scale, const float* d_bn_shift, int32_t pool, float* d_y, void* stream) {
+               int32_t cout, int32_t k, int32_t padding, int32_t dilation, int32_t groups, int32_t stride,
+               int32_t act, const float* d_bn_scale, const float* d_bn_shift, int32_t pool, float* d_y,
+               void* stream) {
     if (n == 0) return OFP_OK;
     OFP_REQUIRE(d_x && d_w && d_y, "ofp_conv1d: NULL argument");
     OFP_REQUIRE(groups >= 1 && cin % groups == 0 && cout % groups == 0,
                 "ofp_conv1d: groups %d must divide cin %d and cout %d", groups, cin, cout);
     OFP_REQUIRE((d_bn_scale == nullptr) == (d_bn_shift == nullptr), "ofp_conv1d: give both bn_scale and bn_shift");
+    OFP_REQUIRE(stride >= 1, "ofp_conv1d: stride %d", stride);
     int wout = w + 2 * padding - dilation * (k - 1);
     OFP_REQUIRE(wout >= 1, "ofp_conv1d: empty output (w=%d k=%d padding=%d dilation=%d)", w, k, padding, dilation);
+    wout = (wout - 1) / stride + 1;
     if (pool) wout /= 2;  // MaxPool1d(kernel_size=2, stride=2), floor
     OFP_REQUIRE(wout >= 1, "ofp_conv1d: nothing left after pooling");
     OFP_REQUIRE(act >= OFP_ACT_IDENTITY && act <= OFP_ACT_TANH, "ofp_conv1d: unknown activation %d", act);
     int64_t total = n * cout * wout;
     unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
     hipLaunchKernelGGL(k_conv1d, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n, cin, w, d_w, d_b, cout,
-                       k, padding, dilation, groups, act, d_bn_scale, d_bn_shift, pool ? 1 : 0, wout, d_y);
+                       k, padding, dilation, groups, stride, act, d_bn_scale, d_bn_shift, pool ? 1 : 0, wout, d_y);
     OFP_LAUNCH_CHECK("k_conv1d");
+    return OFP_OK;
+}
+
+int ofp_groupnorm1(const float* d_x, int64_t n, int32_t K, int32_t V, const float* d_gamma, const float* d_beta,
+                   float eps, int32_t pool, float* d_y, void* stream) {
+    if (n == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_y && d_x != d_y && K >= 1 && V >= 1 && n < (1ll << 31), "ofp_groupnorm1: bad argument");
+    OFP_REQUIRE(!pool || V >= 2, "ofp_groupnorm1: nothing left after pooling");
+    hipLaunchKernelGGL(k_groupnorm1, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, d_x, K, V, d_gamma, d_beta,
+                       eps, pool ? 1 : 0, d_y);
+    OFP_LAUNCH_CHECK("k_groupnorm1");
     return OFP_OK;
 }
 

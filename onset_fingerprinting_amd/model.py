@@ -21,13 +21,13 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def conv1d_forward(x, weight, bias, padding, dilation, act_code, groups=1, bn=None, pool=False):
+def conv1d_forward(x, weight, bias, padding, dilation, act_code, groups=1, bn=None, pool=False, stride=1):
     """Conv1d + bias + activation (+ eval-mode BatchNorm1d `bn` + MaxPool1d(2, 2)): the layer of
     model.py:91-107 in one kernel."""
     L = _lib.lib()
     n, cin, w = x.shape
     cout, _, k = weight.shape
-    wout = w + 2 * padding - dilation * (k - 1)
+    wout = (w + 2 * padding - dilation * (k - 1) - 1) // stride + 1
     if pool:
         wout //= 2
     scale = shift = None
@@ -39,10 +39,24 @@ def conv1d_forward(x, weight, bias, padding, dilation, act_code, groups=1, bn=No
         shift = (b - bn.running_mean.double() * g * inv).to(x.device, torch.float32).contiguous()
     out = torch.empty((n, cout, wout), dtype=torch.float32, device=x.device)
     check(L.ofp_conv1d(x.data_ptr(), n, cin, w, weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                       cout, k, padding, dilation, groups, act_code,
+                       cout, k, padding, dilation, groups, stride, act_code,
                        scale.data_ptr() if scale is not None else None,
                        shift.data_ptr() if shift is not None else None, int(bool(pool)), out.data_ptr(),
                        _stream(x.device)), "ofp_conv1d")
+    return out
+
+
+def groupnorm1_forward(x, gn, pool=False):
+    """nn.GroupNorm(1, K) (+ MaxPool1d(2, 2)) on x float32 CUDA [n, K, V]."""
+    assert gn.num_groups == 1
+    L = _lib.lib()
+    n, K, V = x.shape
+    out = torch.empty((n, K, V // 2 if pool else V), dtype=torch.float32, device=x.device)
+    g = gn.weight.detach().to(x.device, torch.float32).contiguous() if gn.weight is not None else None
+    b = gn.bias.detach().to(x.device, torch.float32).contiguous() if gn.bias is not None else None
+    check(L.ofp_groupnorm1(x.data_ptr(), n, K, V, g.data_ptr() if g is not None else None,
+                           b.data_ptr() if b is not None else None, float(gn.eps), int(bool(pool)), out.data_ptr(),
+                           _stream(x.device)), "ofp_groupnorm1")
     return out
 
 
@@ -52,15 +66,21 @@ def _run_conv_stack(layers, h, to, padding, dilation, act_code, groups):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.Conv1d):
-            bn, pool, j = None, False, i + 1
+            bn, gn, pool, j = None, None, False, i + 1
             while j < len(mods) and not isinstance(mods[j], nn.Conv1d):
                 if isinstance(mods[j], nn.BatchNorm1d):
                     bn = mods[j]
+                elif isinstance(mods[j], nn.GroupNorm):
+                    gn = mods[j]
                 elif isinstance(mods[j], nn.MaxPool1d):
                     pool = True
                 j += 1
+            # conv + bias + activation (+ folded BatchNorm + pool) in one kernel; a GroupNorm needs the
+            # whole item first, so it (and the pool after it) runs as a second kernel
             h = conv1d_forward(h, to(m.weight), to(m.bias) if m.bias is not None else None, padding, dilation,
-                               act_code, groups=groups, bn=bn, pool=pool)
+                               act_code, groups=groups, bn=bn, pool=pool and gn is None, stride=m.stride[0])
+            if gn is not None:
+                h = groupnorm1_forward(h, gn, pool=pool)
             i = j
         else:
             i += 1
@@ -130,8 +150,6 @@ class CCCNN(nn.Module):
             kernel_sizes = [kernel_sizes] * len(layer_sizes)
         if isinstance(strides, int):
             strides = [strides] * len(layer_sizes)
-        if batch_norm or any(s != 1 for s in strides):
-            raise NotImplementedError("batch_norm (GroupNorm) / stride != 1 are not on the accelerated path yet")
         if activation not in ACT_CODES:
             raise ValueError(f"activation {activation} has no HIP implementation")
         self.group, self.channels = group, channels
@@ -139,11 +157,13 @@ class CCCNN(nn.Module):
         self.conv_layers = nn.Sequential()
         g = channels if group else 1  # model.py:466,484: one private stack per sensor channel when grouped
         cur, width = g, input_size
-        for i, (size, k) in enumerate(zip(layer_sizes, kernel_sizes)):
+        for i, (size, k, stride) in enumerate(zip(layer_sizes, kernel_sizes, strides)):
             self.conv_layers.add_module(
-                f"conv{i+1}", nn.Conv1d(cur, size * g, k, padding=padding, dilation=dilation, groups=g))
+                f"conv{i+1}", nn.Conv1d(cur, size * g, k, padding=padding, dilation=dilation, stride=stride, groups=g))
             self.conv_layers.add_module(f"act{i+1}", activation())
-            width = width + 2 * padding - dilation * (k - 1)
+            width = (width + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+            if batch_norm:  # model.py:497-501: a GroupNorm with one group, despite the argument's name
+                self.conv_layers.add_module(f"bn{i+1}", nn.GroupNorm(1, size * g))
             if pool:
                 self.conv_layers.add_module(f"pool{i+1}", nn.MaxPool1d(kernel_size=2, stride=2))
                 width //= 2
@@ -166,3 +186,20 @@ class CCCNN(nn.Module):
         probs = autocorr_softmax(h)  # [B*C, 2V-1]
         out = dense_forward(probs.reshape(B, -1), to(self.fc.weight), to(self.fc.bias), None, None, 0)
         return out if x.is_cuda else out.cpu()
+
+
+class LCCCNN(nn.Module):
+    """``model.LCCCNN`` (model.py:541-580): the training wrapper around CCCNN; inference only here.
+    Parameter names (``model.conv_layers.conv{i}``, ``model.fc``) follow the reference."""
+
+    def __init__(self, input_size: int, output_size: int, channels: int = 3, layer_sizes=[8, 16], kernel_sizes=3,
+                 strides=1, dropout_rate: float = 0.5, batch_norm=False, pool=False, padding=1, dilation=1,
+                 group: bool = False, activation=nn.SiLU, loss=F.l1_loss, lr=1e-3) -> None:
+        super().__init__()
+        self.model = CCCNN(input_size, output_size, channels, layer_sizes, kernel_sizes, strides, dropout_rate,
+                           batch_norm, pool, padding, dilation, group, activation)
+        self.lr = lr
+        self.loss = loss
+
+    def forward(self, x):
+        return self.model(x)

@@ -151,6 +151,7 @@ def g14():
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.running_mean.normal_(0, 0.3)
                 mod.running_var.uniform_(0.5, 2.0)
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.GroupNorm)):
                 mod.weight.data.uniform_(0.5, 1.5)
                 mod.bias.data.normal_(0, 0.2)
         m.eval()

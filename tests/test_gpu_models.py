@@ -70,7 +70,8 @@ def test_cnn_matches_reference_golden():
 
 
 def test_cnn_cccnn_constructor_options_match_reference_golden():
-    """batch_norm (eval), MaxPool, groups, dilation for CNN; group / pool for CCCNN (model.py:62-67, 451-456)."""
+    """batch_norm (eval), MaxPool, groups, dilation for CNN; group / pool / GroupNorm / strides for CCCNN and
+    the LCCCNN configuration of the reference's train.py:79-90 (model.py:62-67, 451-456, 541-580)."""
     from onset_fingerprinting_amd import model
     from tests.golden.make_golden_next_cfg import G14
     g = load_golden("g14_model_variants")
@@ -81,5 +82,3 @@ def test_cnn_cccnn_constructor_options_match_reference_golden():
         m.load_state_dict(sd)  # the reference's own keys, BatchNorm buffers included
         y = m(torch.from_numpy(g[f"{name}/x"])).numpy()
         assert y.shape == g[f"{name}/y"].shape and rel_err(y, g[f"{name}/y"]) < 1e-4, name
-    with pytest.raises(NotImplementedError):
-        model.CCCNN(64, 2, batch_norm=True)
