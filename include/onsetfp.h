@@ -302,6 +302,12 @@ int ofp_group_windows(const float* d_x, int64_t n_clips, int64_t n_samples, int3
 int ofp_xcorr_lag(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n_in, int32_t d, int32_t take_abs,
                   int32_t cutoff, const int32_t* d_lo, const int32_t* d_hi, int32_t* d_argmax, float* d_cc,
                   int32_t cc_stride, void* stream);
+/* Full cross-correlation of row pairs (batch_cc, data.py:226-230; paired_xcorr, model.py:12-45):
+ * d_out[i][j] = sum_t a[i][t + j - (L-1)] b[i][t], j in [0, 2L-1); rows i of d_a / d_b start at
+ * i*a_stride / i*b_stride floats.  mean_k > 1: output row i is the mean of input rows
+ * [i*mean_k, (i+1)*mean_k) (paired_xcorr's mean over feature maps).  length <= 4096. */
+int ofp_xcorr_full(const float* d_a, const float* d_b, int64_t n_rows, int32_t length, int64_t a_stride,
+                   int64_t b_stride, int32_t mean_k, float* d_out, void* stream);
 /* fix_onsets (detection.py:373-451) for every onset group, one workgroup per group:
  * median filter (scipy.ndimage 'reflect') over audio[a-look : b+look], d-th difference,
  * rectification by direction (0 none, 1 "up", 2 "down"), abs, then for every channel after the

@@ -125,6 +125,39 @@ __global__ __launch_bounds__(XT) void k_xcorr_lag(const float* __restrict__ x, c
     if (threadIdx.x == 0) argmax[p] = r;
 }
 
+// Full cross-correlation of row pairs, what the reference gets from a grouped F.conv1d
+// (batch_cc, data.py:226-230; paired_xcorr, model.py:12-45): out[i][j] = sum_t a[i][t + j - (L-1)]
+// * b[i][t], j in [0, 2L-1).  One workgroup per row pair, rows in LDS, one lag per thread, fp32
+// fma over ascending t.  `mean_k` > 1 averages groups of mean_k consecutive rows (the mean over the
+// K feature maps of paired_xcorr) into one output row.
+__global__ __launch_bounds__(XT) void k_xcorr_full(const float* __restrict__ a, const float* __restrict__ b, int L,
+                                                   int64_t a_stride, int64_t b_stride, int mean_k,
+                                                   float* __restrict__ out) {
+    __shared__ float as[X_MAXN], bs[X_MAXN];
+    const int64_t row0 = (int64_t)blockIdx.x * mean_k;
+    const int nl = 2 * L - 1;
+    for (int j0 = 0; j0 < nl; j0 += XT) {  // accumulators for this thread's lags, over the mean_k rows
+        const int j = j0 + threadIdx.x;
+        float acc_mean = 0.0f;
+        for (int m = 0; m < mean_k; ++m) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < L; t += XT) {
+                as[t] = a[(row0 + m) * a_stride + t];
+                bs[t] = b[(row0 + m) * b_stride + t];
+            }
+            __syncthreads();
+            if (j < nl) {
+                const int k = j - (L - 1);
+                const int t0 = k < 0 ? -k : 0, t1 = k > 0 ? L - k : L;
+                float acc = 0.0f;
+                for (int t = t0; t < t1; ++t) acc = fmaf(as[t + k], bs[t], acc);
+                acc_mean += acc;
+            }
+        }
+        if (j < nl) out[(int64_t)blockIdx.x * nl + j] = mean_k > 1 ? acc_mean / (float)mean_k : acc_mean;
+    }
+}
+
 // ---- fix_onsets ---------------------------------------------------------------------------
 struct FixArgs {
     const float* audio;  // [n_clips][N][C]
@@ -341,6 +374,19 @@ int ofp_xcorr_lag(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n
     hipLaunchKernelGGL(k_xcorr_lag, dim3((unsigned)n_pairs), dim3(XT), 0, (hipStream_t)stream, d_x, d_y, n_in, d,
                        take_abs, cutoff, d_lo, d_hi, d_argmax, d_cc, cc_stride);
     OFP_LAUNCH_CHECK("k_xcorr_lag");
+    return OFP_OK;
+}
+
+int ofp_xcorr_full(const float* d_a, const float* d_b, int64_t n_rows, int32_t length, int64_t a_stride,
+                   int64_t b_stride, int32_t mean_k, float* d_out, void* stream) {
+    if (n_rows == 0) return OFP_OK;
+    OFP_REQUIRE(d_a && d_b && d_out && length >= 1 && length <= X_MAXN && mean_k >= 1 && n_rows % mean_k == 0 &&
+                    n_rows / mean_k < (1ll << 31),
+                "ofp_xcorr_full: bad argument (rows=%lld length=%d mean_k=%d; rows of up to %d samples)",
+                (long long)n_rows, length, mean_k, X_MAXN);
+    hipLaunchKernelGGL(k_xcorr_full, dim3((unsigned)(n_rows / mean_k)), dim3(XT), 0, (hipStream_t)stream, d_a, d_b,
+                       length, a_stride, b_stride, mean_k, d_out);
+    OFP_LAUNCH_CHECK("k_xcorr_full");
     return OFP_OK;
 }
 

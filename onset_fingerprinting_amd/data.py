@@ -112,6 +112,19 @@ def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, w
     return (out_power if want_power else None), out_mel
 
 
+def batch_cc(a: torch.Tensor, b: torch.Tensor):
+    """data.py:226-230: full cross-correlation of row i of `a` with row i of `b`,
+    [n, length] x [n, length] -> [n, 2*length - 1] (what the grouped F.conv1d there computes)."""
+    dev = a.device if a.is_cuda else _device(0)
+    to = lambda t: t.detach().to(dev, torch.float32).contiguous()
+    ad, bd = to(a), to(b)
+    n, length = ad.shape
+    out = torch.empty((n, 2 * length - 1), dtype=torch.float32, device=dev)
+    check(_lib.lib().ofp_xcorr_full(ad.data_ptr(), bd.data_ptr(), n, length, length, length, 1, out.data_ptr(),
+                                    _stream(dev)), "ofp_xcorr_full")
+    return out if a.is_cuda else out.cpu()
+
+
 # ---- mel filterbank (librosa's published definition; PARITY UNPINNED, SURVEY 8c) --
 
 def _hz_to_mel(f):

@@ -125,6 +125,23 @@ class CNN(nn.Module):
         return h if x.is_cuda else h.cpu()
 
 
+def paired_xcorr(x: torch.Tensor, C: int, K: int) -> torch.Tensor:
+    """model.py:12-45: cross-correlate every adjacent channel pair (1&2, 2&3, ...) in each feature
+    map and average over the maps: (B, C*K, V) -> (B, C-1, 2V-1)."""
+    B, CK, V = x.shape
+    assert CK == C * K
+    dev = x.device if x.is_cuda else torch.device("cuda", 0)
+    _lib.require_gpu(dev.index or 0)
+    xd = x.detach().to(dev, torch.float32).contiguous().view(B, C, K, V)
+    out = torch.empty((B, C - 1, 2 * V - 1), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    for bi in range(B):  # rows (c, k) of a sample are contiguous: a = channels 0..C-2, b = channels 1..C-1
+        a, b = xd[bi, :-1], xd[bi, 1:]
+        check(L.ofp_xcorr_full(a.data_ptr(), b.data_ptr(), (C - 1) * K, V, V, V, K, out[bi].data_ptr(),
+                               _stream(dev)), "ofp_xcorr_full")
+    return out if x.is_cuda else out.cpu()
+
+
 def autocorr_softmax(feat):
     """feat float32 CUDA [n, K, V] -> [n, 2V-1]: the correlation head of CCCNN (model.py:524-534)."""
     L = _lib.lib()

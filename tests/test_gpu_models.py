@@ -82,3 +82,25 @@ def test_cnn_cccnn_constructor_options_match_reference_golden():
         m.load_state_dict(sd)  # the reference's own keys, BatchNorm buffers included
         y = m(torch.from_numpy(g[f"{name}/x"])).numpy()
         assert y.shape == g[f"{name}/y"].shape and rel_err(y, g[f"{name}/y"]) < 1e-4, name
+
+
+def test_batch_cc_and_paired_xcorr_against_torch():
+    """data.batch_cc (data.py:226-230) and model.paired_xcorr (model.py:12-45): the same grouped
+    F.conv1d expressions evaluated by torch on the CPU are the fp32 reference."""
+    import torch.nn.functional as F
+    from onset_fingerprinting_amd import data, model
+    torch.manual_seed(3)
+    for n, length in ((1, 1), (7, 33), (64, 256), (3, 1000)):
+        a, b = torch.randn(n, length), torch.randn(n, length)
+        ref = F.conv1d(a.reshape(1, n, length), b[:, None, :], padding=length - 1, groups=n)[0]
+        got = data.batch_cc(a, b)
+        assert got.shape == ref.shape and rel_err(got.numpy(), ref.numpy()) < 1e-4
+    for B, C, K, V in ((2, 3, 4, 50), (1, 4, 5, 128), (3, 2, 1, 17)):
+        x = torch.randn(B, C * K, V)
+        xv = x.view(B, C, K, V)
+        a, b = xv[:, :-1].reshape(B, (C - 1) * K, V), xv[:, 1:].reshape(B, (C - 1) * K, V)
+        M = B * (C - 1) * K
+        ref = F.conv1d(F.pad(a, (V - 1, V - 1)).view(1, M, 3 * V - 2), b.reshape(M, 1, V), groups=M)
+        ref = ref.view(B, C - 1, K, 2 * V - 1).mean(dim=2)
+        got = model.paired_xcorr(x, C, K)
+        assert got.shape == ref.shape and rel_err(got.numpy(), ref.numpy()) < 1e-4
