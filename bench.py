@@ -35,10 +35,12 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 from onset_fingerprinting_amd import synth  # noqa: E402
-from onset_fingerprinting_amd.distributed import all_gather_onsets, flatten_records, records_to_numpy  # noqa: E402
+from onset_fingerprinting_amd.distributed import (all_gather_onsets_padded, flatten_records,  # noqa: E402
+                                                  records_to_numpy, unpack_gathered)
 from onset_fingerprinting_amd.pipeline import FingerprintPipeline  # noqa: E402
 
 SR, C, SECONDS, NFFT, HOP, NMELS = 48000, 8, 60.0, 1024, 256, 40
+GATHER_CAP = 4096  # onset records per rank and step in the all-gather block (C2 has 952)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic bytes per frame: every input sample read once, every
 # required output written once
@@ -93,8 +95,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # RCCL ("nccl" on ROCm); OFP_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse the
+        # control flow (RCCL refuses two ranks on one device)
+        backend = os.environ.get("OFP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -128,7 +136,8 @@ def main():
         return out, flat, time.perf_counter() - t_in
 
     def finish(out, flat, lat, timed):
-        gathered = all_gather_onsets(flat)  # the collective, in step order on this thread
+        # the exchange: ONE all-gather of fixed-size blocks (count + records), no host round trip
+        gathered = all_gather_onsets_padded(flat, GATHER_CAP)
         if timed:
             st = dict(out["info"]["stage_ms"])
             st.pop("total")
@@ -177,7 +186,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(n1):
             _, flat1, _ = run_step(w1, False)
-            all_gather_onsets(flat1)
+            all_gather_onsets_padded(flat1, GATHER_CAP)
         barrier()
         t = torch.tensor([(time.perf_counter() - t1) / n1 * 1e3], dtype=torch.float64, device=dev)
         if world > 1:
@@ -186,6 +195,7 @@ def main():
 
     if rank == 0:
         out, power, mel, logits, gathered = res
+        gathered = unpack_gathered(gathered)  # decode (and check) the last step's exchange
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         stage_bytes = dict(hp=BYTES_DETECT, db=BYTES_DETECT, ar=BYTES_DETECT, rel=BYTES_DETECT, mm=BYTES_DETECT // 2,
                            logic=BYTES_DETECT // 2, stft_mel=BYTES_STFT + 4 * NMELS, mlp=BYTES_MLP)

@@ -57,5 +57,32 @@ def all_gather_onsets(local_records, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def all_gather_onsets_padded(local_records, cap, group=None):
+    """One collective, no host round trip: every rank contributes a fixed block of 1 + cap records
+    (record 0 carries the rank's true record count in its `sample` field) and receives
+    [world, 1 + cap, 16] uint8.  Decode with `unpack_gathered` (which checks for truncation)."""
+    dev = local_records.device
+    n = local_records.shape[0]
+    block = torch.zeros((1 + cap, 16), dtype=torch.uint8, device=dev)
+    block[0, 8:16] = torch.tensor([n], dtype=torch.int64, device=dev).view(torch.uint8)
+    m = min(n, cap)
+    block[1:1 + m] = local_records[:m]
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return block[None]
+    world = dist.get_world_size(group)
+    out = torch.empty((world, 1 + cap, 16), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out.view(world * (1 + cap), 16), block, group=group)
+    return out
+
+
+def unpack_gathered(blocks):
+    """[world, 1 + cap, 16] from `all_gather_onsets_padded` -> concatenated records [total, 16]."""
+    cap = blocks.shape[1] - 1
+    counts = blocks[:, 0, 8:16].contiguous().view(torch.int64).reshape(-1).cpu().tolist()
+    if max(counts, default=0) > cap:
+        raise RuntimeError(f"{max(counts)} onset records on a rank exceed the gather capacity {cap}")
+    return torch.cat([blocks[r, 1:1 + c] for r, c in enumerate(counts)], dim=0)
+
+
 def records_to_numpy(flat):
     return flat.cpu().numpy().reshape(-1, 16).view(ONSET_DTYPE).reshape(-1)

@@ -8,8 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from onset_fingerprinting_amd.distributed import (ONSET_DTYPE, all_gather_onsets, flatten_records,
-                                                  records_to_numpy, shard_range)
+from onset_fingerprinting_amd.distributed import (ONSET_DTYPE, all_gather_onsets, all_gather_onsets_padded,
+                                                  flatten_records, records_to_numpy, shard_range, unpack_gathered)
 
 
 def _free_port():
@@ -45,6 +45,15 @@ def _worker(rank, world, port, q):
     lo, hi = shard_range(6, rank, world)
     flat = flatten_records(_as_u8(recs), torch.from_numpy(counts), 8, clip_offset=lo)
     out = all_gather_onsets(flat)
+    # the single-collective form bench.py uses gives the same records
+    padded = unpack_gathered(all_gather_onsets_padded(flat, 16))
+    assert torch.equal(out, padded)
+    try:
+        unpack_gathered(all_gather_onsets_padded(flat, 3))  # rank 1 holds 8 records: truncated
+        truncated_detected = False
+    except RuntimeError:
+        truncated_detected = True
+    assert truncated_detected
     q.put((rank, [tuple(int(v) for v in r) for r in records_to_numpy(out).tolist()]))
     dist.destroy_process_group()
 
@@ -86,3 +95,5 @@ def test_single_process_is_identity():
     recs, counts = _make_records(0)
     flat = flatten_records(_as_u8(recs), torch.from_numpy(counts), 8)
     assert all_gather_onsets(flat) is flat and flat.shape == (7, 16)
+    assert torch.equal(unpack_gathered(all_gather_onsets_padded(flat, 8)), flat)
+
