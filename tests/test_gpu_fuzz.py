@@ -1,0 +1,93 @@
+"""Differential sweep: random detector configurations, inputs and time-parallel tunings, GPU against
+the oracle, onset records and every bit of the relative envelope.  The tunings force the rarely
+taken paths (chain breaks and wrong guesses in the IIR stage, repair cascades in the followers and
+the tracker, runs spanning several chunks, big-batch layouts)."""
+import numpy as np
+import pytest
+
+import oracle
+from onset_fingerprinting_amd import synth
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def random_case(rng):
+    C = int(rng.choice([1, 2, 3, 4, 8, 16]))
+    B = int(rng.choice([32, 64, 128, 256, 512]))
+    secs = float(rng.uniform(1.5, 5.0))
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        x = synth.drum_hits(C, secs, SR, seed=int(rng.integers(1 << 30)), period=float(rng.uniform(0.08, 0.9)))
+    elif kind == 1:
+        x = synth.drum_hits(C, secs, SR, seed=int(rng.integers(1 << 30)), poisson_rate=float(rng.uniform(0.5, 8)),
+                            amp_log_uniform=(0.02, 0.9))
+    elif kind == 2:  # long quiet stretches: the tracker's max is not reset for seconds
+        x = synth.drum_hits(C, secs, SR, seed=int(rng.integers(1 << 30)), period=float(rng.uniform(1.5, 3.0)))
+    elif kind == 3:  # tone + hits: the IIR candidates have little to coalesce at
+        x = synth.drum_hits(C, secs, SR, seed=int(rng.integers(1 << 30)), period=0.7)
+        x += (0.05 * np.sin(2 * np.pi * rng.uniform(2500, 9000) * np.arange(len(x)) / SR))[:, None].astype(np.float32)
+    else:
+        x = (10 ** rng.uniform(-4, -1) * rng.standard_normal((int(secs * SR), C))).astype(np.float32)
+    kw = dict(block_size=B, sr=SR, cooldown=int(rng.choice([0, 20, 1323, 9600])),
+              hipass_freq=float(rng.choice([0.0, 500.0, 2000.0, 6000.0])))
+    if rng.random() < 0.4:
+        kw.update(on_threshold=float(rng.uniform(3, 9)), off_threshold=float(rng.uniform(1.5, 3)))
+    else:
+        kw.update(on_threshold=float(rng.uniform(0.2, 0.7)), off_threshold=float(rng.uniform(0.05, 0.2)))
+    if rng.random() < 0.3:
+        kw.update(fast_ar=(2.0, 966.0), slow_ar=(8000.0, 8000.0))
+    elif rng.random() < 0.3:
+        kw.update(slow_ar=(1500.0, 3000.0))  # asymmetric slow follower: the sequential guess path
+    if rng.random() < 0.25:
+        kw.update(backtrack=True, backtrack_buffer_size=int(max(B, rng.choice([128, 512, 1024]))),
+                  backtrack_smooth_size=int(rng.choice([3, 5, 9])))
+    tuning = {}
+    if rng.random() < 0.7:
+        tuning["hp_chunk"] = int(rng.choice([1024, 2048, 4096, 8192]))
+        tuning["hp_warm"] = int(rng.choice([0, 2048, 8192, 40960])) or -1
+        tuning["hp_candidates"] = int(rng.choice([1, 2, 4, 8, 16]))
+        tuning["hp_span"] = int(rng.choice([1, 2, 4]))
+        tuning["hp_candidate_offset"] = int(rng.choice([-1, 1, 8, 1021]))
+    if rng.random() < 0.5:
+        tuning["ar_chunk"] = int(rng.choice([512, 1024, 4096]))
+        tuning["ar_warm"] = int(rng.choice([1024, 8192, 24576]))
+        tuning["ar_guess"] = int(rng.choice([0, 1]))
+    if rng.random() < 0.5:
+        tuning["mm_chunk"] = int(rng.choice([1024, 4096, 8192]))
+        tuning["mm_warm"] = int(rng.choice([0, 4096, 49152])) or -1
+    return x, kw, tuning
+
+
+def test_random_configurations_match_the_oracle(capsys):
+    from onset_fingerprinting_amd import detection
+    rng = np.random.default_rng(20261004)
+    n_onsets = 0
+    for case in range(120):
+        x, kw, tuning = random_case(rng)
+        recs, rel, info = detection.detect_batch(x[None], tuning=tuning or None, **kw)
+        c, o, orel = oracle.detect_onsets_amplitude(x, **kw)
+        msg = (case, x.shape, kw, tuning)
+        assert np.array_equal(recs[0]["channel"], np.array(c, np.int64)), msg
+        assert np.array_equal(recs[0]["sample"], np.array(o, np.int64)), msg
+        assert np.array_equal(bits(rel[0]), bits(orel)), msg
+        n_onsets += len(c)
+    assert n_onsets > 1000
+
+
+def test_random_batches_of_clips():
+    """Several clips per call (the big-batch layout heuristics) against the oracle clip by clip."""
+    from onset_fingerprinting_amd import detection
+    rng = np.random.default_rng(77)
+    for n_clips, C, secs in ((7, 4, 2.0), (40, 2, 1.5), (3, 16, 3.0)):
+        x = np.stack([synth.drum_hits(C, secs, SR, seed=int(rng.integers(1 << 30)), period=float(rng.uniform(0.1, 0.6)))
+                      for _ in range(n_clips)])
+        recs, rel, _ = detection.detect_batch(x, block_size=128, sr=SR)
+        for i in range(n_clips):
+            c, o, orel = oracle.detect_onsets_amplitude(x[i], block_size=128, sr=SR)
+            assert np.array_equal(recs[i]["channel"], np.array(c, np.int64)) and np.array_equal(recs[i]["sample"], np.array(o, np.int64))
+            assert np.array_equal(bits(rel[i]), bits(orel))
