@@ -646,7 +646,7 @@ struct HpCand {
                       // inner boundaries, so a chunk whose start matched a candidate is run by S
                       // lanes at once (its candidate's trajectory is exact all the way through)
     uint32_t* M;      // [clips][chunks][C][R][S-1][4] those states
-    uint8_t* nxt;     // [clips][chunks][C][R+1] slot of chunk k matching E[k-1][r], 255 none
+    uint8_t* nxt;     // [clips][C][chunks][R+1] slot of chunk k matching E[k-1][r], 255 none
     uint8_t* guessed; // [clips][chunks][C] sel[] is an unverified plurality guess (see k_hp_resolve)
     int8_t* ran;      // [clips][chunks][C] slot whose trajectory produced the chunk's output (R: whole run
                       // from the true start state): lets a re-walk keep outputs whose start did not change
@@ -766,7 +766,9 @@ __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
             }
         }
     }
-    a.nxt[id] = res;
+    // chain-major layout [clip][c][k][r]: the rows k0..k0+63 of one chain that k_hp_resolve stages
+    // are contiguous bytes
+    a.nxt[(((clip * C + c) * a.st.n_chunks + k) * R1) + rp] = res;
 }
 
 // The slot of chunk k whose END state is shared by the most candidates (at least two), -1 if
@@ -799,9 +801,10 @@ __device__ int hp_plurality(const HpCand& a, int64_t clip, int64_t k, int c) {
 // case): nothing else to do.  Wrong: slot R is selected and every later chunk of the chain is
 // invalidated and walked again.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
-    __shared__ uint8_t tile[64 * (HP_MAXR + 1)];
-    __shared__ int8_t stile[64], rtile[64];
-    __shared__ uint8_t redo[64];
+    constexpr int RT = 512;  // chunks staged per tile (one tile covers a whole C2 chain)
+    __shared__ uint8_t tile[RT * (HP_MAXR + 1)];
+    __shared__ int8_t stile[RT], rtile[RT];
+    __shared__ uint8_t redo[RT];
     const int C = a.st.g.C, R1 = a.R + 1;
     const int64_t chain = blockIdx.x;  // clip*C + c
     const int c = (int)(chain % C);
@@ -846,17 +849,17 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     int cur = a.sel[(clip * nk + kstart - 1) * C + c];  // slot chosen for the previous chunk
     bool stuck = false;
     int64_t reached = nk;
-    for (int64_t k0 = kstart; k0 < nk && !stuck; k0 += 64) {
-        const int nblk = (int)min<int64_t>(64, nk - k0);
+    for (int64_t k0 = kstart; k0 < nk && !stuck; k0 += RT) {
+        const int nblk = (int)min<int64_t>(RT, nk - k0);
         __syncthreads();
-        for (int i = lane; i < nblk * R1; i += 64) {
-            const int bk = i / R1, r = i % R1;
-            tile[i] = a.nxt[(((clip * nk + k0 + bk) * C + c) * R1) + r];
+        {
+            const uint8_t* src = a.nxt + ((clip * C + c) * nk + k0) * R1;  // nblk * R1 contiguous bytes
+            for (int i = lane; i < nblk * R1; i += 64) tile[i] = src[i];
         }
-        if (lane < nblk) {
-            stile[lane] = a.sel[(clip * nk + k0 + lane) * C + c];
-            rtile[lane] = a.ran[(clip * nk + k0 + lane) * C + c];
-            redo[lane] = 0;
+        for (int i = lane; i < nblk; i += 64) {
+            stile[i] = a.sel[(clip * nk + k0 + i) * C + c];
+            rtile[i] = a.ran[(clip * nk + k0 + i) * C + c];
+            redo[i] = 0;
         }
         __syncthreads();
         int bk = 0;  // uniform: next chunk of the tile to visit
@@ -894,10 +897,10 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             bk = brk + 1;
         }
         __syncthreads();
-        if (lane < nblk) {
-            const int64_t ci = (clip * nk + k0 + lane) * C + c;
-            a.sel[ci] = stile[lane];
-            if (redo[lane])
+        for (int i = lane; i < nblk; i += 64) {
+            const int64_t ci = (clip * nk + k0 + i) * C + c;
+            a.sel[ci] = stile[i];
+            if (redo[i])
                 for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
         }
     }
