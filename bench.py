@@ -35,7 +35,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 from onset_fingerprinting_amd import synth  # noqa: E402
-from onset_fingerprinting_amd.distributed import (all_gather_onsets_padded, flatten_records,  # noqa: E402
+from onset_fingerprinting_amd.distributed import (all_gather_blocks, pack_block,  # noqa: E402
                                                   records_to_numpy, unpack_gathered)
 from onset_fingerprinting_amd.pipeline import FingerprintPipeline  # noqa: E402
 
@@ -129,15 +129,15 @@ def main():
         t_in = time.perf_counter()
         with torch.cuda.stream(streams[w]):
             out = pipes[w].run(xd, timed=timed)
-            # this rank's onset records, compacted into a tensor of their own (the pipeline's
-            # buffers are free for its next step as soon as this thread returns)
-            flat = flatten_records(out["records"], out["counts"], out["cap"], clip_offset=rank)
+            # this rank's onset records as the fixed block the exchange uses, in a tensor of its own
+            # (no host round trip; the pipeline's buffers are free for its next step on return)
+            flat = pack_block(out["records"], out["counts"], GATHER_CAP, clip_offset=rank)
         streams[w].synchronize()
         return out, flat, time.perf_counter() - t_in
 
     def finish(out, flat, lat, timed):
         # the exchange: ONE all-gather of fixed-size blocks (count + records), no host round trip
-        gathered = all_gather_onsets_padded(flat, GATHER_CAP)
+        gathered = all_gather_blocks(flat)
         if timed:
             st = dict(out["info"]["stage_ms"])
             st.pop("total")
@@ -186,7 +186,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(n1):
             _, flat1, _ = run_step(w1, False)
-            all_gather_onsets_padded(flat1, GATHER_CAP)
+            all_gather_blocks(flat1)
         barrier()
         t = torch.tensor([(time.perf_counter() - t1) / n1 * 1e3], dtype=torch.float64, device=dev)
         if world > 1:

@@ -57,22 +57,45 @@ def all_gather_onsets(local_records, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+def pack_block(records, counts, cap, clip_offset=0):
+    """Detector output of ONE clip -> the fixed block `all_gather_onsets_padded` exchanges, built
+    without a host round trip: records [1, cap_det, 16] uint8, counts [1] int64 -> [1 + cap, 16]
+    (record 0 carries the count; rows beyond it are don't-care)."""
+    assert records.shape[0] == 1, "pack_block handles one clip per rank and step; use flatten_records otherwise"
+    dev = records.device
+    block = torch.zeros((1 + cap, 16), dtype=torch.uint8, device=dev)
+    m = min(cap, records.shape[1])
+    block[1:1 + m] = records[0, :m]
+    if clip_offset:
+        clip = block[1:, :4].contiguous().view(torch.int32)
+        clip += int(clip_offset)
+        block[1:, :4] = clip.view(torch.uint8)
+    block[0, 8:16] = counts[:1].to(torch.int64).view(torch.uint8)
+    return block
+
+
+def all_gather_blocks(block, group=None):
+    """All-gather of one fixed block [1 + cap, 16] per rank (see `pack_block`) -> [world, 1 + cap, 16]:
+    one collective, no host round trip."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return block[None]
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(block.shape), dtype=torch.uint8, device=block.device)
+    dist.all_gather_into_tensor(out.view(world * block.shape[0], 16), block, group=group)
+    return out
+
+
 def all_gather_onsets_padded(local_records, cap, group=None):
-    """One collective, no host round trip: every rank contributes a fixed block of 1 + cap records
-    (record 0 carries the rank's true record count in its `sample` field) and receives
-    [world, 1 + cap, 16] uint8.  Decode with `unpack_gathered` (which checks for truncation)."""
+    """`all_gather_blocks` for already flattened records [n, 16]: every rank contributes 1 + cap
+    records (record 0 carries its true count in the `sample` field).  Decode with `unpack_gathered`
+    (which checks for truncation)."""
     dev = local_records.device
     n = local_records.shape[0]
     block = torch.zeros((1 + cap, 16), dtype=torch.uint8, device=dev)
     block[0, 8:16] = torch.tensor([n], dtype=torch.int64, device=dev).view(torch.uint8)
     m = min(n, cap)
     block[1:1 + m] = local_records[:m]
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return block[None]
-    world = dist.get_world_size(group)
-    out = torch.empty((world, 1 + cap, 16), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out.view(world * (1 + cap), 16), block, group=group)
-    return out
+    return all_gather_blocks(block, group)
 
 
 def unpack_gathered(blocks):

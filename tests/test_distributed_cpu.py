@@ -8,8 +8,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from onset_fingerprinting_amd.distributed import (ONSET_DTYPE, all_gather_onsets, all_gather_onsets_padded,
-                                                  flatten_records, records_to_numpy, shard_range, unpack_gathered)
+from onset_fingerprinting_amd.distributed import (ONSET_DTYPE, all_gather_blocks, all_gather_onsets,
+                                                  all_gather_onsets_padded, flatten_records, pack_block,
+                                                  records_to_numpy, shard_range, unpack_gathered)
 
 
 def _free_port():
@@ -96,4 +97,9 @@ def test_single_process_is_identity():
     flat = flatten_records(_as_u8(recs), torch.from_numpy(counts), 8)
     assert all_gather_onsets(flat) is flat and flat.shape == (7, 16)
     assert torch.equal(unpack_gathered(all_gather_onsets_padded(flat, 8)), flat)
+    # one clip per rank and step: the block is built without flattening (what bench.py does)
+    one = _as_u8(recs)[2:3]
+    blk = pack_block(one, torch.from_numpy(counts[2:3]), 6, clip_offset=4)
+    want = flatten_records(one, torch.from_numpy(counts[2:3]), 8, clip_offset=4)
+    assert torch.equal(unpack_gathered(all_gather_blocks(blk)), want)
 
