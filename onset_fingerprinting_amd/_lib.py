@@ -155,12 +155,18 @@ def last_error():
     return lib().ofp_last_error().decode(errors="replace")
 
 
+_checked = {}
+
+
 def require_gpu(device=0):
-    """Fail loudly unless `device` is a gfx950 GPU."""
+    """Fail loudly unless `device` is a gfx950 GPU (checked once per device and process)."""
+    if device in _checked:
+        return _checked[device]
     L = lib()
     n = L.ofp_device_count()
     if n <= 0:
         raise OnsetFPError(f"no GPU visible to HIP ({last_error()}); onset_fingerprinting_amd has no CPU path")
     buf = ctypes.create_string_buffer(64)
     check(L.ofp_device_check(device, buf, 64), "ofp_device_check")
-    return buf.value.decode()
+    _checked[device] = buf.value.decode()
+    return _checked[device]
