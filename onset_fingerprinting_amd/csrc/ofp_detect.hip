@@ -648,6 +648,7 @@ struct HpCand {
     uint32_t* M;      // [clips][chunks][C][R][S-1][4] those states
     uint8_t* nxt;     // [clips][C][chunks][R+1] slot of chunk k matching E[k-1][r], 255 none
     uint8_t* guessed; // [clips][chunks][C] sel[] is an unverified plurality guess (see k_hp_resolve)
+    int8_t* gs;       // [clips][C][chunks] plurality slot of each chunk's end states (k_hp_plurality), -1 none
     int8_t* ran;      // [clips][chunks][C] slot whose trajectory produced the chunk's output (R: whole run
                       // from the true start state): lets a re-walk keep outputs whose start did not change
     int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
@@ -771,40 +772,55 @@ __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
     a.nxt[(((clip * C + c) * a.st.n_chunks + k) * R1) + rp] = res;
 }
 
-// The slot of chunk k whose END state is shared by the most candidates (at least two), -1 if
-// all end states differ.  Candidates that agree with each other have merged, and then almost
-// surely with the true trajectory as well: a guess that k_hp_resolve verifies afterwards.
-// Whole wave: lane r < R holds candidate r.
-__device__ int hp_plurality(const HpCand& a, int64_t clip, int64_t k, int c) {
-    const int lane = threadIdx.x & 63;
+// pass A2 (once per call): gs[k] = the slot of chunk k whose END state is shared by the most
+// candidates (at least two), -1 if all end states differ.  Candidates that agree with each other
+// have merged, and then almost surely with the true trajectory as well: the guess k_hp_resolve
+// continues from at a break (and verifies afterwards).  16 lanes per chunk, lane r holds candidate r.
+__global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items) {
+    const int64_t id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // (chain, k), k fastest
+    const int r = threadIdx.x & 15;
+    const bool live = id < n_items;
+    const int64_t nk = a.st.n_chunks;
+    const int64_t k = live ? id % nk : 0, chain = live ? id / nk : 0;
+    const int C = a.st.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
     uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-    if (lane < a.R) {
-        const uint32_t* e = a.E + a.slot(clip, k, c, lane);
+    if (live && r < a.R) {
+        const uint32_t* e = a.E + a.slot(clip, k, c, r);
         e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
     }
     int cnt = 0;
     for (int q = 0; q < a.R; ++q)
-        cnt += (__shfl(e0, q) == e0 && __shfl(e1, q) == e1 && __shfl(e2, q) == e2 && __shfl(e3, q) == e3) ? 1 : 0;
-    // most votes, lowest slot on ties; key = cnt * 64 + (63 - lane)
-    int key = (lane < a.R && cnt >= 2) ? cnt * 64 + (63 - lane) : -1;
-    for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
-    return key < 0 ? -1 : 63 - (key & 63);
+        cnt += (__shfl(e0, q, 16) == e0 && __shfl(e1, q, 16) == e1 && __shfl(e2, q, 16) == e2 &&
+                __shfl(e3, q, 16) == e3) ? 1 : 0;
+    // most votes, lowest slot on ties; key = cnt * 16 + (15 - r)
+    int key = (r < a.R && cnt >= 2) ? cnt * 16 + (15 - r) : -1;
+    for (int o = 8; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 16));
+    if (live && r == 0) a.gs[chain * nk + k] = (int8_t)(key < 0 ? -1 : 15 - (key & 15));
 }
 
-// pass B2: one wave per chain walks the match table (staged through LDS in tiles).
+// pass B2: one wave per chain resolves which slot every chunk starts from.
+//
+// sel[k] = nxt[k][sel[k-1]]: a chain of table look-ups, i.e. a composition of maps
+// f_k : slot -> slot, which is associative -- so instead of walking the chain, each lane composes
+// the maps of its 8 consecutive chunks, a 6-step scan composes those across the wave, and every
+// lane then knows the slot entering its segment and fills it in.
 //
 // A chunk k whose true start state E[k-1][sel] matches none of its candidates is a break: it has
 // to be run from that state before its end state is known, which costs a round.  Instead of
-// stopping there, the walk continues from the plurality end state of chunk k (hp_plurality) and
-// marks the chunk `guessed`; k_hp_run runs chunk k from its true start state in the same round
-// (slot R), and the NEXT resolve compares that exact end state with the guess.  Right (the usual
-// case): nothing else to do.  Wrong: slot R is selected and every later chunk of the chain is
-// invalidated and walked again.  Results stay exact; only the number of rounds changes.
+// stopping there, f_k continues from the plurality end state of chunk k (gs[k]) and the chunk is
+// marked `guessed`; k_hp_run runs chunk k from its true start state in the same round (slot R),
+// and the NEXT resolve compares that exact end state with the guess.  Right (the usual case):
+// nothing else to do.  Wrong: slot R is selected, the later chunks of the chain are resolved again
+// and those whose start state actually changed are run again.  Without a plurality the chain is
+// stuck at k until the next round.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
-    constexpr int RT = 512;  // chunks staged per tile (one tile covers a whole C2 chain)
+    constexpr int SEG = 8, RT = 64 * SEG;       // chunks per lane, per tile
+    constexpr int NV = HP_MAXR + 2, STUCK = HP_MAXR + 1;  // map domain: slots 0..R, STUCK
     __shared__ uint8_t tile[RT * (HP_MAXR + 1)];
-    __shared__ int8_t stile[RT], rtile[RT];
-    __shared__ uint8_t redo[RT];
+    __shared__ int8_t stile[RT], rtile[RT], gtile[RT];
+    __shared__ uint8_t maps[2][64][NV];
     const int C = a.st.g.C, R1 = a.R + 1;
     const int64_t chain = blockIdx.x;  // clip*C + c
     const int c = (int)(chain % C);
@@ -835,7 +851,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             if (k == wrong) {
                 a.sel[ci] = (int8_t)a.R;
             } else {
-                a.sel[ci] = -1;  // walked again below; outputs are dropped only where the start changes
+                a.sel[ci] = -1;  // resolved again below; outputs are dropped only where the start changes
             }
         }
         if (lane == 0) a.pos[chain] = (int32_t)(wrong + 1);
@@ -847,9 +863,16 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     // resume where the previous round stopped: chunks before pos[] are resolved
     const int64_t kstart = max<int64_t>(1, a.pos[chain]);
     int cur = a.sel[(clip * nk + kstart - 1) * C + c];  // slot chosen for the previous chunk
-    bool stuck = false;
-    int64_t reached = nk;
-    for (int64_t k0 = kstart; k0 < nk && !stuck; k0 += RT) {
+    int64_t reached = nk;  // first chunk left unresolved (uniform)
+    // f_k(v): the slot chunk k+1 starts from when chunk k starts from v
+    auto step = [&](int i, int v) -> int {
+        if (stile[i] >= 0) return stile[i];  // resolved in an earlier round
+        if (v == STUCK) return STUCK;
+        const uint8_t m = tile[i * R1 + v];
+        if (m != 255) return m;
+        return gtile[i] >= 0 ? gtile[i] : STUCK;
+    };
+    for (int64_t k0 = kstart; k0 < nk && reached == nk; k0 += RT) {
         const int nblk = (int)min<int64_t>(RT, nk - k0);
         __syncthreads();
         {
@@ -859,54 +882,69 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
         for (int i = lane; i < nblk; i += 64) {
             stile[i] = a.sel[(clip * nk + k0 + i) * C + c];
             rtile[i] = a.ran[(clip * nk + k0 + i) * C + c];
-            redo[i] = 0;
+            gtile[i] = a.gs[chain * nk + k0 + i];
         }
         __syncthreads();
-        int bk = 0;  // uniform: next chunk of the tile to visit
-        while (bk < nblk) {
-            int brk = -1;  // chunk of the tile where lane 0 met a break
-            if (lane == 0) {
-                for (; bk < nblk; ++bk) {
-                    int s = stile[bk];
-                    if (s < 0) {
-                        const uint8_t m = tile[bk * R1 + cur];
-                        if (m == 255) { brk = bk; break; }
-                        s = m;
-                        stile[bk] = (int8_t)s;
-                        if (rtile[bk] != s) redo[bk] = 1;  // output (if any) came from another start
-                    }
-                    cur = s;
+        // 1. the map of this lane's segment [s0, s1)
+        const int s0 = min(lane * SEG, nblk), s1 = min(s0 + SEG, nblk);
+        for (int v = 0; v < NV; ++v) {
+            int w = (v <= a.R || v == STUCK) ? v : STUCK;
+            for (int i = s0; i < s1; ++i) w = step(i, w);
+            maps[0][lane][v] = (uint8_t)w;
+        }
+        __syncthreads();
+        // 2. inclusive scan over the lanes: maps[b][l] = segment 0 .. l composed
+        int b = 0;
+        for (int o = 1; o < 64; o <<= 1) {
+            for (int v = 0; v < NV; ++v)
+                maps[b ^ 1][lane][v] = lane >= o ? maps[b][lane][maps[b][lane - o][v]] : maps[b][lane][v];
+            __syncthreads();
+            b ^= 1;
+        }
+        // 3. the slot entering this lane's segment, then the segment itself
+        int v = lane == 0 ? cur : maps[b][lane - 1][cur];
+        int first_stuck = RT;  // index in the tile of the chunk the chain is stuck at
+        for (int i = s0; i < s1; ++i) {
+            if (stile[i] >= 0) {
+                v = stile[i];
+                continue;
+            }
+            if (v == STUCK) break;  // an earlier chunk is stuck: this one stays unresolved
+            const uint8_t m = tile[i * R1 + v];
+            const int64_t ci = (clip * nk + k0 + i) * C + c;
+            int sv;
+            bool redo = false;
+            if (m != 255) {
+                sv = m;
+                redo = rtile[i] != sv;  // its output (if any) came from another start
+            } else {
+                redo = true;  // a break is run whole from its (new) true start
+                if (gtile[i] >= 0) {
+                    sv = gtile[i];
+                    a.guessed[ci] = 1;
+                    pending = true;
+                } else {
+                    sv = -1;
+                    first_stuck = i;
                 }
             }
-            brk = __shfl(brk, 0);
-            if (brk < 0) break;
-            // break: continue from the plurality end state, if there is one (whole wave)
-            const int gs = hp_plurality(a, clip, k0 + brk, c);
-            if (lane == 0) redo[brk] = 1;  // a break is run whole from its (new) true start
-            if (gs < 0) {
-                stuck = true;
-                reached = k0 + brk;
+            if (redo)
+                for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+            if (sv < 0) {
+                v = STUCK;
                 break;
             }
-            if (lane == 0) {
-                stile[brk] = (int8_t)gs;
-                a.guessed[(clip * nk + k0 + brk) * C + c] = 1;
-                pending = true;
-                cur = gs;
-            }
-            bk = brk + 1;
+            a.sel[ci] = (int8_t)sv;
+            v = sv;
         }
-        __syncthreads();
-        for (int i = lane; i < nblk; i += 64) {
-            const int64_t ci = (clip * nk + k0 + i) * C + c;
-            a.sel[ci] = stile[i];
-            if (redo[i])
-                for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
-        }
+        for (int o = 32; o > 0; o >>= 1) first_stuck = min(first_stuck, __shfl_xor(first_stuck, o));
+        if (first_stuck < RT) reached = k0 + first_stuck;
+        cur = maps[b][63][cur];  // the slot entering the next tile (meaningless once stuck)
+        pending = __any(pending);
     }
     if (lane == 0) {
         a.pos[chain] = (int32_t)reached;
-        if (stuck) atomicAdd(a.counters, 1);
+        if (reached < nk) atomicAdd(a.counters, 1);
         if (pending) atomicAdd(a.counters + 1, 1);
     }
 }
@@ -1375,7 +1413,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, total;
 };
 
@@ -1463,6 +1501,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_nxt = take(cc * (l.hp_R + 1));
         l.o_hp_guess = take(cc);
         l.o_hp_ran = take(cc);
+        l.o_hp_gs = take(cc);
         l.o_hp_pos = take(n_clips * g.C * 4);
     }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
@@ -1686,11 +1725,13 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.nxt = reinterpret_cast<uint8_t*>(ws + l.o_hp_nxt);
         hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
         hc.ran = reinterpret_cast<int8_t*>(ws + l.o_hp_ran);
+        hc.gs = reinterpret_cast<int8_t*>(ws + l.o_hp_gs);
         hc.counters = d_changed;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
+        const int64_t nC0 = chains * l.hp_chunks;
         if (phase != 2) {
             OFP_HIP(hipMemsetAsync(hc.pos, 0, chains * 4, stream));
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
@@ -1703,6 +1744,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
         hp_cand_timed = true;
         if (phase == 1) return OFP_OK;
+        hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
+        OFP_LAUNCH_CHECK("k_hp_plurality");
         for (int it = 0;; ++it) {
             OFP_HIP(hipMemsetAsync(d_changed, 0, 2 * sizeof(int), stream));
             hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
