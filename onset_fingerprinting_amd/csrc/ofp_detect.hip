@@ -1442,7 +1442,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // for chunk length until the launch is about two waves per SIMD.
     const int64_t chains = n_clips * g.C;
     const int64_t lane_budget = 2 * 4 * 64 * (int64_t)d->n_cus;
-    int64_t hpL = 8192, hpR = 16, arL = 4096, mmL = 8192;
+    int64_t hpL = 8192, hpR = 16, arL = 4096, mmL = 4096;
     if (d->t.hp_chunk <= 0 && d->t.hp_candidates <= 0) {
         if (chains * cdiv(g.V, hpL) * hpR > lane_budget) hpR = 8;  // fewer leave too many chain breaks
         while (hpL < 65536 && chains * cdiv(g.V, hpL) * hpR > lane_budget) hpL *= 2;
