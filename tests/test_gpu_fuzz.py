@@ -91,3 +91,30 @@ def test_random_batches_of_clips():
             c, o, orel = oracle.detect_onsets_amplitude(x[i], block_size=128, sr=SR)
             assert np.array_equal(recs[i]["channel"], np.array(c, np.int64)) and np.array_equal(recs[i]["sample"], np.array(o, np.int64))
             assert np.array_equal(bits(rel[i]), bits(orel))
+
+
+def test_random_groups_and_fix_onsets():
+    """find_onset_groups / fix_onsets with random parameters against the oracle (exact)."""
+    from onset_fingerprinting_amd import detection
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        n, C = int(rng.integers(1, 400)), int(rng.integers(1, 12))
+        on = np.sort(rng.integers(0, 200000, n)) if rng.random() < 0.8 else rng.integers(0, 200000, n)
+        ch = rng.integers(0, C, n)
+        md, mc = int(rng.choice([0, 10, 300, 1000, 10 ** 7])), int(rng.integers(1, C + 2))
+        cc = None if rng.random() < 0.5 else int(rng.integers(0, int(ch.max()) + 1))
+        got = detection.find_onset_groups(on.tolist(), ch.tolist(), md, mc, cc)
+        want = oracle.find_onset_groups(on, ch, md, mc, cc)
+        assert (got is None) == (want is None), case
+        if want is not None:
+            assert np.array_equal(got, want), case
+    with np.errstate(all="ignore"):
+        for case in range(12):
+            C = int(rng.integers(2, 9))
+            audio, on = synth.sensor_hits(int(rng.integers(1 << 30)), n_channels=C, n=30000, hits=int(rng.integers(3, 14)),
+                                          jitter=int(rng.integers(0, 25)))
+            kw = dict(filter_size=int(rng.choice([1, 3, 5, 7])), d=int(rng.choice([0, 1, 2])),
+                      onset_direction=[None, "up", "down"][int(rng.integers(0, 3))], take_abs=bool(rng.integers(0, 2)),
+                      zero_left=bool(rng.integers(0, 2)), normalization_cutoff=int(rng.choice([5, 10, 25])),
+                      onset_tolerance=int(rng.choice([10, 30, 45])), shift_onsets=int(rng.choice([0, 3, -2])))
+            assert np.array_equal(detection.fix_onsets(audio, on, **kw), oracle.fix_onsets(audio, on, **kw)), (case, kw)
