@@ -187,9 +187,9 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     float2* twF = twM + M;
     float* win = reinterpret_cast<float*>(twF + M + 2);
     float2* bufs = reinterpret_cast<float2*>(win + F);
-    // mel epilogue: power of the workgroup's frames [FPW][M+2], then the filterbank
-    float* pw = reinterpret_cast<float*>(bufs + (size_t)FPW * 2 * M);
-    float* fw = pw + (size_t)FPW * (M + 2);
+    // mel epilogue: the filterbank; a frame's power spectrum goes into whichever of its two FFT
+    // buffers the result is NOT in (M+1 floats fit into M float2), so it costs no LDS of its own
+    float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * 2 * M);
     int32_t* flo = reinterpret_cast<int32_t*>(fw + mf.nnz);
     int32_t* flen = flo + mf.n_mels;
     int32_t* foff = flen + mf.n_mels;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         float2* Z = cfft<M, T>(A, Bf, twM, tid);
         if (valid) {
             float* dst = power ? power + f * (M + 1) : nullptr;
-            float* pf = pw + (size_t)sub * (M + 2);
+            float* pf = reinterpret_cast<float*>(Z == A ? Bf : A);
             for (int k = tid; k <= M; k += T) {
                 float2 X = rfft_bin<M>(Z, twF, k);
                 const float p = X.x * X.x + X.y * X.y;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         if (mf.mel) {
             __syncthreads();
             if (valid) {
-                const float* pf = pw + (size_t)sub * (M + 2);
+                const float* pf = reinterpret_cast<const float*>(Z == A ? Bf : A);
                 for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
                     const float* p = pf + flo[b];
                     const float* wb = fw + foff[b];
@@ -388,7 +388,7 @@ int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, i
                  const MelFuse& mf, int planar, hipStream_t stream) {
     using G = Cfg<F>;
     size_t lds = G::lds_bytes;
-    if (mf.mel) lds += (size_t)G::FPW * (G::M + 2) * 4 + (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
+    if (mf.mel) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
     static size_t attr_set = 0;
     if (lds > 65536 && lds > attr_set) {
         OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F>),
