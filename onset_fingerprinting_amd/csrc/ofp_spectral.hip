@@ -74,23 +74,35 @@ __device__ __forceinline__ void dftR(float2* v) {
     else dft2(v[0], v[1]);
 }
 
-// one Stockham pass of radix R: M points, Ns = product of the radices already done
+// One Stockham pass of radix R over M points held in ONE buffer: every lane first reads the
+// inputs of all its butterflies into registers, a workgroup barrier separates the reads from the
+// writes, so the autosort permutation needs no second buffer (half the LDS per frame, more
+// workgroups per CU).  Ns = product of the radices already done.
 template <int R, int M, int T>
-__device__ __forceinline__ void fft_pass(const float2* in, float2* out, const float2* tw, int Ns, int tid) {
-#pragma unroll 1
-    for (int j = tid; j < M / R; j += T) {
-        const int k = j & (Ns - 1);
-        float2 v[R];
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
+    constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
+    static_assert((M / R) % T == 0 && NB >= 1, "lanes per frame must divide the butterflies of a pass");
+    float2 v[NB][R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = in[j + i * (M / R)];
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[b][i] = buf[j + i * (M / R)];
+    }
+    __syncthreads();  // all reads of this pass are done
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+        const int k = j & (Ns - 1);
         const int tstep = k * (M / (Ns * R));
 #pragma unroll
-        for (int i = 1; i < R; ++i) v[i] = cmul(v[i], tw[(i * tstep) & (M - 1)]);
-        dftR<R>(v);
+        for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
+        dftR<R>(v[b]);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int i = 0; i < R; ++i) out[j0 + i * Ns] = v[i];
+        for (int i = 0; i < R; ++i) buf[j0 + i * Ns] = v[b][i];
     }
+    __syncthreads();  // all writes are visible to the next pass
 }
 
 template <int M> struct Radices;
@@ -100,22 +112,19 @@ template <> struct Radices<512>  { static constexpr int n = 3; static constexpr 
 template <> struct Radices<1024> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
 template <> struct Radices<2048> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
 
-// complex FFT of the M points in bufA (all T lanes of the frame group call this
-// together; `sync` is a workgroup barrier).  Returns the buffer holding the result.
+// complex FFT, in place, of the M points in `a` (every thread of the workgroup calls this
+// together: the passes contain workgroup barriers).
 template <int M, int T>
-__device__ __forceinline__ float2* cfft(float2* a, float2* b, const float2* tw, int tid) {
+__device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
     using Rx = Radices<M>;
     int Ns = 1;
+    __syncthreads();  // the frame has been written
 #pragma unroll
     for (int p = 0; p < Rx::n; ++p) {
-        __syncthreads();
-        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, b, tw, Ns, tid);
-        else fft_pass<4, M, T>(a, b, tw, Ns, tid);
+        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
+        else fft_pass<4, M, T>(a, tw, Ns, tid);
         Ns *= Rx::r[p];
-        float2* t = a; a = b; b = t;
     }
-    __syncthreads();
-    return a;
 }
 
 template <int F>
@@ -124,8 +133,8 @@ struct Cfg {
     static constexpr int T = (M / 8) < 16 ? 16 : (M / 8);   // lanes per frame
     static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
-    // LDS: twM[M] + twF[M+1] (float2), window[F] (float), 2 buffers of M float2 per frame
-    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * 2 * M * 8;
+    // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
+    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * M * 8;
 };
 
 template <int F>
@@ -187,9 +196,9 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     float2* twF = twM + M;
     float* win = reinterpret_cast<float*>(twF + M + 2);
     float2* bufs = reinterpret_cast<float2*>(win + F);
-    // mel epilogue: the filterbank; a frame's power spectrum goes into whichever of its two FFT
-    // buffers the result is NOT in (M+1 floats fit into M float2), so it costs no LDS of its own
-    float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * 2 * M);
+    // mel epilogue: the filterbank; a frame's power spectrum is written back into its FFT buffer
+    // (M+1 floats fit into M float2) once every lane holds its bins in registers
+    float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * M);
     int32_t* flo = reinterpret_cast<int32_t*>(fw + mf.nnz);
     int32_t* flen = flo + mf.n_mels;
     int32_t* foff = flen + mf.n_mels;
@@ -204,8 +213,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     build_tables<F>(twM, twF, win, F);
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
-    float2* A = bufs + (size_t)sub * 2 * M;
-    float2* Bf = A + M;
+    float2* A = bufs + (size_t)sub * M;
     const int64_t n_groups = cdiv(total_frames, FPW);
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
@@ -227,21 +235,32 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
                 A[n] = make_float2(a, b);
             }
         }
-        float2* Z = cfft<M, T>(A, Bf, twM, tid);
-        if (valid) {
-            float* dst = power ? power + f * (M + 1) : nullptr;
-            float* pf = reinterpret_cast<float*>(Z == A ? Bf : A);
-            for (int k = tid; k <= M; k += T) {
-                float2 X = rfft_bin<M>(Z, twF, k);
-                const float p = X.x * X.x + X.y * X.y;
-                if (dst) dst[k] = p;
-                if (mf.mel) pf[k] = p;
+        cfft<M, T>(A, twM, tid);
+        constexpr int NK = M / T + 1;  // bins per lane: k = tid, tid + T, ... <= M
+        float pk[NK];
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = tid + q * T;
+            pk[q] = 0.0f;
+            if (k <= M) {
+                const float2 X = rfft_bin<M>(A, twF, k);
+                pk[q] = X.x * X.x + X.y * X.y;
             }
         }
+        if (valid && power) {
+            float* dst = power + f * (M + 1);
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+                if (tid + q * T <= M) dst[tid + q * T] = pk[q];
+        }
         if (mf.mel) {
+            __syncthreads();  // every bin of the spectrum has been read
+            float* pf = reinterpret_cast<float*>(A);
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+                if (tid + q * T <= M) pf[tid + q * T] = pk[q];
             __syncthreads();
             if (valid) {
-                const float* pf = reinterpret_cast<const float*>(Z == A ? Bf : A);
                 for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
                     const float* p = pf + flo[b];
                     const float* wb = fw + foff[b];
@@ -285,8 +304,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
     for (int n = threadIdx.x; n < F; n += blockDim.x) win[n] = a.window[n];
     const int sub = threadIdx.x / T;
     const int tid = threadIdx.x % T;
-    float2* A = bufs + (size_t)sub * 2 * M;
-    float2* Bf = A + M;
+    float2* A = bufs + (size_t)sub * M;
     const int lpad = (F - a.frame_length) / 2;  // librosa.util.pad_center (data.py:588-589)
     const int64_t n_groups = cdiv(a.n_frames, FPW);
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -311,10 +329,10 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
                 A[n] = make_float2(v[0], v[1]);
             }
         }
-        float2* Z = cfft<M, T>(A, Bf, twM, tid);
+        cfft<M, T>(A, twM, tid);
         if (valid) {
             float2* dst = a.spec + f * (M + 1);
-            for (int k = tid; k <= M; k += T) dst[k] = rfft_bin<M>(Z, twF, k);
+            for (int k = tid; k <= M; k += T) dst[k] = rfft_bin<M>(A, twF, k);
         }
     }
 }
