@@ -215,11 +215,15 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     const int tid = threadIdx.x % T;
     float2* A = bufs + (size_t)sub * M;
     const int64_t n_groups = cdiv(total_frames, FPW);
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
-        const bool valid = f < total_frames;
-        __syncthreads();  // tables ready / previous iteration's reads done
-        if (valid) {
+    // the samples of a frame are fetched one iteration ahead into registers, so that the global
+    // loads of frame g+1 are in flight while frame g goes through the FFT
+    constexpr int NP = M / T;  // sample pairs per lane
+    float2 nx[NP];
+    auto fetch = [&](int64_t grp) {
+        const int64_t f = grp * FPW + sub;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) nx[q] = make_float2(0.0f, 0.0f);
+        if (grp < n_groups && f < total_frames) {
             const int64_t h = f % H;
             const int64_t cc = f / H;  // clip*C + c
             const int c = (int)(cc % C);
@@ -229,12 +233,24 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             // floats: the detector's transposed copy, 8x less L2 traffic at C = 8)
             const int64_t stride = planar ? 1 : C;
             const float* src = planar ? x + cc * n_samples + h * hop : x + (clip * n_samples + h * hop) * C + c;
-            for (int n = tid; n < M; n += T) {
-                float a = src[(int64_t)(2 * n) * stride] * win[2 * n];
-                float b = src[(int64_t)(2 * n + 1) * stride] * win[2 * n + 1];
-                A[n] = make_float2(a, b);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int n = tid + q * T;
+                nx[q] = make_float2(src[(int64_t)(2 * n) * stride], src[(int64_t)(2 * n + 1) * stride]);
             }
         }
+    };
+    fetch(blockIdx.x);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
+        const bool valid = f < total_frames;
+        __syncthreads();  // tables ready / previous iteration's reads done
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int n = tid + q * T;
+            A[n] = make_float2(nx[q].x * win[2 * n], nx[q].y * win[2 * n + 1]);
+        }
+        fetch(grp + gridDim.x);
         cfft<M, T>(A, twM, tid);
         constexpr int NK = M / T + 1;  // bins per lane: k = tid, tid + T, ... <= M
         float pk[NK];
