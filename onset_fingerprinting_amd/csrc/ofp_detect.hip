@@ -43,6 +43,12 @@
 
 #include "ofp_detector.h"
 
+// The speculative IIR kernel keeps one VALU-bound wave on most SIMDs for ~1.7 ms; with several
+// steps in flight the short, dependent-latency-bound kernels of the other steps land on the same
+// SIMDs.  They raise their wave priority so that their (sparse) instructions issue first and the
+// long kernel fills the gaps, instead of both halving.
+#define OFP_LATENCY_BOUND_KERNEL() __builtin_amdgcn_s_setprio(3)
+
 namespace {
 
 using ofp::align_up;
@@ -333,6 +339,7 @@ struct ArArgs {
 //   k_ar_chunk : pass 0 runs every chunk from used[k]; pass j >= 1 re-runs the chunks whose
 //                used[k] differs bitwise from end[k-1], from end[k-1]
 __global__ __launch_bounds__(64) void k_ar_coarse(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;       // chunk fastest: neighbouring lanes do equal work
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(64) void k_ar_coarse(ArArgs a, int64_t n_threads, u
 // fast follower starts from the floor, and the warm-up is long enough to forget that.
 // Only a guess: the chunk passes verify every state bit for bit.
 __global__ __launch_bounds__(64) void k_ar_sym_local(ArArgs a, int64_t n_waves, double* __restrict__ P) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = blockIdx.x;  // one wave per (chain, chunk)
     if (id >= n_waves) return;
     const int lane = threadIdx.x;
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(64) void k_ar_sym_local(ArArgs a, int64_t n_waves, 
 
 __global__ __launch_bounds__(64) void k_ar_sym_combine(ArArgs a, const double* __restrict__ P,
                                                        uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
     __shared__ double sp[1024];
     __shared__ float ss[1024];
     const int64_t chain = blockIdx.x;
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(64) void k_ar_sym_combine(ArArgs a, const double* _
 }
 
 __global__ __launch_bounds__(64) void k_ar_warm(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_t
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
                                                  int* changed) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -509,6 +520,7 @@ constexpr int64_t MM_WARM_FULL = 12288;
 // (first half of the grid) WHILE the min runs its short one alone (second half), each at the speed
 // of a one-word step.
 __global__ __launch_bounds__(64) void k_mm_warm2(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t half = (n_threads + 63) / 64;  // blocks per half
     const bool is_min = blockIdx.x >= half;
     const int64_t id = ((int64_t)blockIdx.x - (is_min ? half : 0)) * blockDim.x + threadIdx.x;
@@ -536,6 +548,7 @@ __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_t
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
                                                  int* changed) {
+    OFP_LATENCY_BOUND_KERNEL();
     // launched with 2 * ceil(nt / 64) workgroups: the first half carries the max, the second the min
     const int64_t nt = a.n_chains * a.n_chunks;
     const int64_t half = (nt + 63) / 64;
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_t
 __global__ __launch_bounds__(64) void k_mm_maxpass(MmArgs a, int64_t n_threads, const uint32_t* __restrict__ end_prev,
                                                    uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
                                                    int* changed) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -767,6 +781,7 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
 
 // pass B1: nxt[k][c][r_prev] for every chunk k >= 1 (parallel)
 __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_items) return;
     const int R1 = a.R + 1;
@@ -799,6 +814,7 @@ __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
 // have merged, and then almost surely with the true trajectory as well: the guess k_hp_resolve
 // continues from at a break (and verifies afterwards).  16 lanes per chunk, lane r holds candidate r.
 __global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // (chain, k), k fastest
     const int r = threadIdx.x & 15;
     const bool live = id < n_items;
@@ -838,6 +854,7 @@ __global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items)
 // and those whose start state actually changed are run again.  Without a plurality the chain is
 // stuck at k until the next round.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
+    OFP_LATENCY_BOUND_KERNEL();
     constexpr int SEG = 8, RT = 64 * SEG;       // chunks per lane, per tile
     constexpr int NV = HP_MAXR + 2, STUCK = HP_MAXR + 1;  // map domain: slots 0..R, STUCK
     __shared__ uint8_t tile[RT * (HP_MAXR + 1)];
@@ -978,6 +995,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
 // a chunk that starts from an unmatched state (a break, guessed or not) or whose own slot is the
 // exact re-run has no such states and is run whole by lane 0.
 __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
@@ -1107,6 +1125,7 @@ struct ScanArgs {
 // One wave per (chain, block), lanes over the rows of the block (coalesced); the first crossing
 // and the last row below `off` come out of two ballots per 64 rows.
 __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int C = a.g.C, B = a.g.B;
     const int lane = threadIdx.x & 63;
     const int64_t total = a.n_clips * a.nb * C;
@@ -1162,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
 // (-1: none yet).  One wave per (clip, channel), 64 blocks per step.
 __global__ __launch_bounds__(64) void k_last_clear(const int32_t* __restrict__ lb, int32_t* __restrict__ pc,
                                                    int64_t nb, int C) {
+    OFP_LATENCY_BOUND_KERNEL();
     const int64_t chain = blockIdx.x;
     const int c = (int)(chain % C);
     const int64_t clip = chain / C;
@@ -1196,6 +1216,7 @@ struct VisArgs {
 };
 
 __global__ __launch_bounds__(256) void k_visits(VisArgs a) {
+    OFP_LATENCY_BOUND_KERNEL();
     __shared__ int s_w[4];
     const int64_t clip = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1253,6 +1274,7 @@ struct SmArgs {
 constexpr int SM_NPL = 16;  // table entries per lane per tile (TB*C <= 64*SM_NPL)
 
 __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
+    OFP_LATENCY_BOUND_KERNEL();
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = a.g.C, B = a.g.B;
     const int64_t clip = blockIdx.x;
@@ -1425,6 +1447,8 @@ __global__ __launch_bounds__(64) void k_backtrack(BtArgs a) {
 
 // ---------------------------------------------------------------------------
 // host side
+constexpr int OFP_N_COUNTERS = 512;  // int slots at the head of the zeroed region
+
 struct Layout {
     Geom g;
     int64_t nb;
@@ -1436,7 +1460,7 @@ struct Layout {
     int tu;  // time steps per transpose tile
     // byte offsets
     int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
-        o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, total;
+        o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, o_zero, zero_bytes, total;
 };
 
 int64_t pick(int64_t user, int64_t dflt) { return user > 0 ? user : dflt; }
@@ -1524,37 +1548,59 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_guess = take(cc);
         l.o_hp_ran = take(cc);
         l.o_hp_gs = take(cc);
-        l.o_hp_pos = take(n_clips * g.C * 4);
     }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
     l.o_ar_P = take(n_clips * l.ar_chunks * g.C * 8);
     l.o_mm_state = take(3 * n_clips * l.mm_chunks * g.C * 2 * 4);
-    l.o_mm_dirty = take(n_clips * l.mm_chunks * g.C);
     l.o_thr_mn = take(n_clips * l.nb * g.C * 4);
     l.o_thr_mx = take(n_clips * l.nb * g.C * 4);
     l.o_first = take(n_clips * l.nb * g.C * 4);
     l.o_last = take(n_clips * l.nb * g.C * 4);
-    l.o_vflag = take(n_clips * l.nb * 4);
     l.o_pc = take(n_clips * l.nb * g.C * 4);
     l.o_visj = take(n_clips * l.nb * 4);
     l.o_vrec = take(3 * n_clips * l.nb * g.C * 4);
     l.o_nv = take(n_clips * 4);
-    l.o_flags = take(256);
+    // everything that has to start a call as zero lies in one region: one fill per call
+    l.o_flags = take(OFP_N_COUNTERS * 4);  // pass / round counters, one fresh slot per use
+    l.o_zero = l.o_flags;
+    l.o_hp_pos = take(n_clips * g.C * 4);
+    l.o_mm_dirty = take(n_clips * l.mm_chunks * g.C);
+    l.o_vflag = take(n_clips * l.nb * 4);
+    l.zero_bytes = o - l.o_zero;
     l.total = o;
     return l;
 }
+
+// Zeroed int counters for the verification passes: the region is cleared once per call and every
+// use takes a fresh slot (the last slot is recycled with a fill when a call needs more).
+struct Counters {
+    int* base;
+    int next;
+    hipStream_t stream;
+    int take(int n, int** out) {  // n <= 2
+        if (next + n <= OFP_N_COUNTERS - 2) {
+            *out = base + next;
+            next += n;
+            return OFP_OK;
+        }
+        *out = base + OFP_N_COUNTERS - 2;
+        OFP_HIP(hipMemsetAsync(*out, 0, 2 * sizeof(int), stream));
+        return OFP_OK;
+    }
+};
 
 // chunk-Jacobi driver: `chunk` kernel pass 0 (from used[]), then verification/repair passes
 // until a pass changes nothing.  used[] has been filled by the stage's warm-up kernels.
 template <class K, class A>
 int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
-               int* d_changed, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired,
+               Counters& ctr, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired,
                void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, hipStream_t) = nullptr,
                int64_t words = 0) {
     if (words == 0) words = n_threads * 2;  // state words per array
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
     const unsigned grid = (unsigned)cdiv(n_threads, 64);
+    int* d_changed = ctr.base;  // pass 0 counts nothing
     hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
                        d_changed);
     OFP_LAUNCH_CHECK(name);
@@ -1563,7 +1609,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
     uint32_t* prev = endA;
     uint32_t* next = endB;
     for (int pass = 1;; ++pass) {
-        OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+        if (int rc = ctr.take(1, &d_changed)) return rc;
         hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass, n_threads, (const uint32_t*)prev, next,
                            used, d_changed);
         OFP_LAUNCH_CHECK(name);
@@ -1578,7 +1624,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
             return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name, changed, pass);
         if (light_pass) {  // a cascade is under way: light passes, eight per host round trip
             for (int group = 0; group < 4096; ++group) {
-                OFP_HIP(hipMemsetAsync(d_changed, 0, sizeof(int), stream));
+                if (int rc = ctr.take(1, &d_changed)) return rc;
                 for (int q = 0; q < 8; ++q) {
                     light_pass(args, n_threads, prev, next, used, d_changed, stream);
                     std::swap(prev, next);
@@ -1700,7 +1746,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     float* xt = reinterpret_cast<float*>(ws + l.o_xt);
     float* xdb = reinterpret_cast<float*>(ws + l.o_xdb);
     float* dif = reinterpret_cast<float*>(ws + l.o_dif);
-    int* d_changed = reinterpret_cast<int*>(ws + l.o_flags);
+    Counters ctr{reinterpret_cast<int*>(ws + l.o_flags), 0, stream};
     int64_t info[OFP_DETECT_INFO_LEN] = {0};
     hipEvent_t* ev = d->ev;
     if (phase != 2) OFP_HIP(hipEventRecord(ev[0], stream));
@@ -1719,6 +1765,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
 
     // --- transpose in
     if (phase != 2) {
+        OFP_HIP(hipMemsetAsync(ws + l.o_zero, 0, (size_t)l.zero_bytes, stream));  // counters, flags: see make_layout
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
                            stream, d_x, xt, N, g.C, l.tu);
         OFP_LAUNCH_CHECK("k_transpose_in");
@@ -1749,14 +1796,13 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
         hc.ran = reinterpret_cast<int8_t*>(ws + l.o_hp_ran);
         hc.gs = reinterpret_cast<int8_t*>(ws + l.o_hp_gs);
-        hc.counters = d_changed;
+        hc.counters = ctr.base;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
         const int64_t nC0 = chains * l.hp_chunks;
         if (phase != 2) {
-            OFP_HIP(hipMemsetAsync(hc.pos, 0, chains * 4, stream));
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
             if ((int64_t)cand_grid <= d->n_cus)
                 hipLaunchKernelGGL(k_hp_candidates<true>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
@@ -1770,13 +1816,13 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
         OFP_LAUNCH_CHECK("k_hp_plurality");
         for (int it = 0;; ++it) {
-            OFP_HIP(hipMemsetAsync(d_changed, 0, 2 * sizeof(int), stream));
+            if (int rc = ctr.take(2, &hc.counters)) return rc;
             hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
             OFP_LAUNCH_CHECK("k_hp_match");
             hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
             OFP_LAUNCH_CHECK("k_hp_resolve");
             int* flags = d->h_flags;  // chains stuck at a break / chains with unverified guesses
-            OFP_HIP(hipMemcpyAsync(flags, d_changed, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            OFP_HIP(hipMemcpyAsync(flags, hc.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
             hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
             OFP_LAUNCH_CHECK("k_hp_run");
             OFP_HIP(hipStreamSynchronize(stream));
@@ -1826,7 +1872,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
         hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_ar_warm");
-        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, d_changed, d->h_flags, d->t.max_passes,
+        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
                             stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
@@ -1862,10 +1908,9 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nt = chains * l.mm_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
-        OFP_HIP(hipMemsetAsync(a.dirty, 0, nt, stream));
         hipLaunchKernelGGL(k_mm_warm2, dim3(2 * grid), dim3(64), 0, stream, a, nt, used);
         OFP_LAUNCH_CHECK("k_mm_warm2");
-        int rc = run_jacobi("tracker stage", k_mm_chunk, a, 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, d_changed, d->h_flags,
+        int rc = run_jacobi("tracker stage", k_mm_chunk, a, 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, ctr, d->h_flags,
                             d->t.max_passes, stream, &info[2], &info[3],
                             +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch,
                                 hipStream_t st) {
@@ -1895,8 +1940,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sa.vflag = reinterpret_cast<uint32_t*>(ws + l.o_vflag);
     {
         const int64_t total = n_clips * l.nb * g.C;
-        OFP_HIP(hipMemsetAsync(sa.vflag, 0, n_clips * l.nb * 4, stream));
-        const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
+            const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
         hipLaunchKernelGGL(k_block_scan, dim3(bs_grid), dim3(256), 0, stream, sa);
         OFP_LAUNCH_CHECK("k_block_scan");
     }
