@@ -42,6 +42,7 @@ from onset_fingerprinting_amd.pipeline import FingerprintPipeline  # noqa: E402
 SR, C, SECONDS, NFFT, HOP, NMELS = 48000, 8, 60.0, 1024, 256, 40
 GATHER_CAP = 4096  # onset records per rank and step in the all-gather block (C2 has 952)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_NOFMA_PEAK_TFLOPS = 157.3 / 2  # the guide's fp32 vector peak counts an FMA as two operations
 # algorithmic bytes per frame: every input sample read once, every
 # required output written once
 BYTES_DETECT = 2 * 4 * HOP                 # 4 B read + 4 B rel write per sample
@@ -52,7 +53,7 @@ BYTES_MLP = 4 * NMELS + 4 * 8
 # WRITE_SIZE, /opt/skills/guides/MI355X_MICROARCH.md section HBM); filled from profiles/, else null
 TRAFFIC_BYTES_PER_LAUNCH = {}
 try:  # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), see profiles/README.md
-    _t = json.load(open(REPO / "profiles" / "r01" / "v11_pmc_traffic_per_kernel.json"))
+    _t = json.load(open(REPO / "profiles" / "r01" / "v12_pmc_traffic_per_kernel.json"))
     TRAFFIC_BYTES_PER_LAUNCH = {"hp": _t["k_hp_candidates"]["hbm_mb_per_launch"] * 1e6,
                                 "stft_mel": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
 except Exception:
@@ -224,8 +225,8 @@ def main():
                        "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
                        "one_step_at_a_time": {"ms_per_step": round(single_ms, 3),
                                               "frames_per_s": round(world * frames_per_rank / (single_ms / 1e3))}},
-            "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_coarse+k_ar_warm+k_ar_chunk",
-                                                    "mm": "k_mm_max+k_mm_warm+k_mm_chunk", "db": "k_rect_db",
+            "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm+k_ar_chunk",
+                                                    "mm": "k_mm_warm2+k_mm_chunk", "db": "k_rect_db",
                                                     "rel": "k_rel_out", "logic": "k_block_scan+k_state_machine",
                                                     "stft_mel": "k_stft_power<1024> (mel fused)", "mlp": "k_dense"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -236,6 +237,15 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "detector_passes": {k: passes[k] for k in ("hp_passes", "ar_passes", "mm_passes", "repaired")},
         }
+        if dom == "hp" and cand_ms > 0 and passes.get("hp_candidate_steps"):
+            # what actually bounds k_hp_candidates: the fp32 operations of its speculative IIR steps (17 each,
+            # no FMA: every operation is rounded as the reference rounds it) against the vector fp32 rate
+            # without FMA (157.3 TFLOP/s counts an FMA as 2)
+            flop = 17.0 * passes["hp_candidate_steps"]
+            tf = flop / (cand_ms / 1e3) / 1e12
+            result["roofline"]["issue"] = {"bound": "valu fp32 without fma", "flop_per_launch": flop,
+                                           "achieved": tf, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": tf / VALU_NOFMA_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(x, min(args.cpu_seconds, SECONDS))
             # parity of the timed GPU result against the oracle on the same sample

@@ -149,7 +149,8 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  * passes, 3: repaired chunks, 4..9: nanoseconds (HIP events on `stream`) spent in
  * the hp, dB, follower, linear, tracker and crossing/state-machine stages,
  * 10: total nanoseconds, 11: nanoseconds of the k_hp_candidates launch (the longest
- * single launch)}. */
+ * single launch), 12: IIR steps that launch executes over all its lanes (17 fp32
+ * operations each)}. */
 #define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,

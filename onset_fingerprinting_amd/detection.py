@@ -186,7 +186,8 @@ class BatchDetector:
             # stage durations, HIP events on the launch stream (milliseconds)
             stage_ms=dict(hp=info[4] / 1e6, db=info[5] / 1e6, ar=info[6] / 1e6, rel=info[7] / 1e6,
                           mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6,
-                          hp_candidates=info[11] / 1e6))
+                          hp_candidates=info[11] / 1e6),
+            hp_candidate_steps=info[12])
         out["cap"] = cap
         return out
 
