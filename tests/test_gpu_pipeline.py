@@ -88,6 +88,55 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
             assert got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1]))
 
 
+def test_c2_at_full_size_matches_the_oracle_bit_for_bit(mods):
+    """BASELINE config C2 at its full size (8 ch x 60 s, block 256): onset records and the whole
+    relative envelope against the oracle (1.2 s of CPU)."""
+    detection, _ = mods
+    x = synth.c2_drums(60.0, 8, SR, seed=1)
+    xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
+    bd = detection.BatchDetector(8, 256, sr=SR)
+    out = bd.detect(xd)
+    n = int(out["counts"][0])
+    recs = detection.BatchDetector.records_to_numpy(out)[0]
+    ch, on, orel = oracle.detect_onsets_amplitude(x, block_size=256, sr=SR)
+    assert n == len(ch) and n > 900
+    assert np.array_equal(recs["channel"], np.asarray(ch)) and np.array_equal(recs["sample"], np.asarray(on))
+    assert np.array_equal(bits(out["rel"][0].cpu().numpy()), bits(orel))
+
+
+def test_c3_size_properties_tuning_independence_and_channel_subsets(mods):
+    """C3's channel count and block size at 64 ch x 100 s (the oracle would need seconds per
+    channel-minute here): the result does not depend on the time-parallel tuning (the batch-adaptive
+    layout picks 8 candidates and long chunks at this size; a second detector is forced to the
+    small-batch layout), a second run repeats the first, and a clip made of the first 3 channels
+    padded with silent ones gives channel-for-channel the same envelope for those 3 (`rel` of a
+    channel depends on that channel alone; only the hysteresis couples channels)."""
+    detection, _ = mods
+    x = synth.c2_drums(100.0, 64, SR, seed=2)
+    xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
+    ref = None
+    for tuning in (None, dict(hp_chunk=8192, hp_candidates=16, ar_chunk=4096, mm_chunk=4096), None):
+        bd = detection.BatchDetector(64, 512, sr=SR)
+        if tuning:
+            bd.set_tuning(**tuning)
+        out = bd.detect(xd)
+        n = int(out["counts"][0])
+        got = (out["records"].cpu().numpy()[:, :n].copy(), out["rel"].cpu().numpy().copy())
+        if ref is None:
+            ref = got
+            assert n > 5000
+        else:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1]))
+    sub = np.zeros_like(x[:, :8])
+    sub[:, :3] = x[:, :3]
+    bd = detection.BatchDetector(8, 512, sr=SR)
+    out = bd.detect(torch.from_numpy(sub).cuda().unsqueeze(0).contiguous())
+    assert np.array_equal(bits(out["rel"][0, :, :3].cpu().numpy()), bits(ref[1][0, :, :3]))
+    # ... and the oracle agrees on a 5 s prefix of 4 of the 64 channels' envelopes
+    ch, on, orel = oracle.detect_onsets_amplitude(np.ascontiguousarray(x[: 5 * SR, :4]), block_size=512, sr=SR)
+    assert np.array_equal(bits(ref[1][0, : orel.shape[0], :4]), bits(orel))
+
+
 def test_c5_streaming_per_hop_in_a_hip_graph(mods):
     """2-channel stream fed hop by hop (B = 256) through ONE captured graph per hop
     (copy-in -> k_stream); the onsets and the relative envelope equal the oracle's."""
