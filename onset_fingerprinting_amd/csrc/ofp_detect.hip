@@ -1810,18 +1810,18 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 hipLaunchKernelGGL(k_hp_candidates<false>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
             OFP_LAUNCH_CHECK("k_hp_candidates");
             OFP_HIP(hipEventRecord(ev[7], stream));
-            {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
-                int64_t steps = 0;
-                const int Rm = hc.R / hc.span;
-                for (int64_t j = 0; j < l.hp_chunks; ++j) {
-                    const int64_t run_end = std::min<int64_t>((j + hc.span) * l.hp_L, g.V);
-                    for (int r = 0; r < Rm; ++r)
-                        steps += run_end - std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
-                }
-                info[12] = steps * chains;
-            }
         }
         hp_cand_timed = true;
+        {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
+            int64_t steps = 0;
+            const int Rm = hc.R / hc.span;
+            for (int64_t j = 0; j < l.hp_chunks; ++j) {
+                const int64_t run_end = std::min<int64_t>((j + hc.span) * l.hp_L, g.V);
+                for (int r = 0; r < Rm; ++r)
+                    steps += run_end - std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
+            }
+            info[12] = steps * chains;
+        }
         if (phase == 1) return OFP_OK;
         hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
         OFP_LAUNCH_CHECK("k_hp_plurality");
