@@ -1187,16 +1187,25 @@ __global__ __launch_bounds__(64) void k_last_clear(const int32_t* __restrict__ l
     const int64_t clip = chain / C;
     const int lane = threadIdx.x;
     int carry = -1;
-    for (int64_t j0 = 0; j0 < nb; j0 += 64) {
-        const int64_t j = j0 + lane;
-        int v = (j < nb && lb[(clip * nb + j) * C + c] >= 0) ? (int)j : -1;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(v, o);
-            if (lane >= o) v = max(v, t);
+    constexpr int U = 4;  // 4 x 64 blocks per step: the loads are issued together, the scans follow
+    for (int64_t j0 = 0; j0 < nb; j0 += 64 * U) {
+        int v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + 64 * u + lane;
+            v[u] = (j < nb && lb[(clip * nb + j) * C + c] >= 0) ? (int)j : -1;
         }
-        v = max(v, carry);
-        if (j < nb) pc[(clip * nb + j) * C + c] = v;
-        carry = __shfl(v, 63);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + 64 * u + lane;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v[u], o);
+                if (lane >= o) v[u] = max(v[u], t);
+            }
+            v[u] = max(v[u], carry);
+            if (j < nb) pc[(clip * nb + j) * C + c] = v[u];
+            carry = __shfl(v[u], 63);
+        }
     }
 }
 
@@ -1218,6 +1227,7 @@ struct VisArgs {
 __global__ __launch_bounds__(256) void k_visits(VisArgs a) {
     OFP_LATENCY_BOUND_KERNEL();
     __shared__ int s_w[4];
+    __shared__ uint8_t s_idx[4][64];  // per wave: lane of its q-th visited block
     const int64_t clip = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
@@ -1227,25 +1237,25 @@ __global__ __launch_bounds__(256) void k_visits(VisArgs a) {
         const bool f = j < a.nb && a.vflag[clip * a.nb + j] != 0u;
         const unsigned long long m0 = __ballot(f);
         if (lane == 0) s_w[wave] = __popcll(m0);
+        if (f) s_idx[wave][__popcll(m0 & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         __syncthreads();
         int woff = 0, tot = 0;
         for (int w = 0; w < 4; ++w) {
             if (w < wave) woff += s_w[w];
             tot += s_w[w];
         }
-        unsigned long long m = m0;
-        while (m) {  // the wave copies one visited block's record at a time, lanes over channels
-            const int l = __builtin_ctzll(m);
-            const int64_t jj = j0 + wave * 64 + l;
-            const int64_t pos = clip * a.nb + base + woff + __popcll(m0 & ((1ull << l) - 1ull));
-            if (lane == 0) a.vis_j[pos] = (int32_t)jj;
-            for (int c = lane; c < C; c += 64) {
-                const int64_t src = (clip * a.nb + jj) * C + c;
-                a.vfc[pos * C + c] = a.fc[src];
-                a.vlb[pos * C + c] = a.lb[src];
-                a.vpc[pos * C + c] = jj > 0 ? a.pc[src - C] : -1;
-            }
-            m &= m - 1;
+        // the wave copies the records of its visited blocks, lanes over (visited block, channel):
+        // all loads of a step are independent
+        const int n_el = __popcll(m0) * C;
+        for (int e = lane; e < n_el; e += 64) {
+            const int q = e / C, c = e - q * C;
+            const int64_t jj = j0 + wave * 64 + s_idx[wave][q];
+            const int64_t pos = clip * a.nb + base + woff + q;
+            if (c == 0) a.vis_j[pos] = (int32_t)jj;
+            const int64_t src = (clip * a.nb + jj) * C + c;
+            a.vfc[pos * C + c] = a.fc[src];
+            a.vlb[pos * C + c] = a.lb[src];
+            a.vpc[pos * C + c] = jj > 0 ? a.pc[src - C] : -1;
         }
         base += tot;
         __syncthreads();
