@@ -84,8 +84,8 @@ def cpu_baseline(x, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=6, help="steps (clips) processed concurrently per GPU")
