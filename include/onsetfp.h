@@ -183,6 +183,18 @@ int ofp_stream_process(ofp_detector* det, void* d_state, const float* d_x, int64
                        int64_t n_rows, int32_t warmup, int64_t sample_base, float* d_rel,
                        ofp_onset* d_records, int64_t cap, int64_t* d_count, void* stream);
 
+/* AmplitudeOnsetDetector.init (detection.py:842-888), the passes over the samples, with the state in
+ * d_state: high-pass over the n_rows rows of d_x (:849-850), unclipped rectified dB (:852), the
+ * followers over rows [r0, r1) (the settling blocks, :855-860), over all rows with
+ * d_rel[n_rows][C] = fast - slow in dB (:862-867), and over rows n_rev-1 .. 0 (:883-888).
+ * d_scratch [n_rows][C].  Tracker and hysteresis state are untouched.  The thresholds init derives
+ * from statistics of d_rel (:869-872) are installed with ofp_detector_set_thresholds.  Only enqueues. */
+int ofp_stream_calibrate(ofp_detector* det, void* d_state, const float* d_x, int64_t n_rows, int64_t r0,
+                         int64_t r1, int64_t n_rev, float* d_scratch, float* d_rel, void* stream);
+/* Replaces the per-channel thresholds given to ofp_detector_create (host arrays of C doubles);
+ * synchronous.  Applies to launches enqueued afterwards. */
+int ofp_detector_set_thresholds(ofp_detector* det, const double* on_threshold, const double* off_threshold);
+
 /* ---- framing + STFT (data.py:55-120, 581-654) ------------------------------------ */
 /* Dense power spectra, the metric's frame definition (one frame per hop):
  *   d_x [n_clips][n_samples][C] interleaved;  frame h of channel c covers samples

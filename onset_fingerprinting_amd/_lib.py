@@ -86,6 +86,8 @@ SIGNATURES = {
     "ofp_stream_state_bytes": (_i64, [_vp]),
     "ofp_stream_state_init": (ctypes.c_int, [_vp, _vp, _vp]),
     "ofp_stream_process": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "ofp_stream_calibrate": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ofp_detector_set_thresholds": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ofp_stft_power": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ofp_stft_power_mel": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                           _i32, _vp]),

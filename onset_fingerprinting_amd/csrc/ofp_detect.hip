@@ -1717,6 +1717,23 @@ int ofp_detector_destroy(ofp_detector* d) {
     return OFP_OK;
 }
 
+int ofp_detector_set_thresholds(ofp_detector* d, const double* on_threshold, const double* off_threshold) {
+    OFP_REQUIRE(d && on_threshold && off_threshold, "ofp_detector_set_thresholds: NULL argument");
+    const int C = d->p.n_channels;
+    d->on.assign(on_threshold, on_threshold + C);
+    d->off.assign(off_threshold, off_threshold + C);
+    std::vector<float> onf(C), offf(C);
+    for (int c = 0; c < C; ++c) {
+        onf[c] = (float)on_threshold[c];
+        offf[c] = (float)off_threshold[c];
+    }
+    // blocking copies: the arrays are read by launches the caller enqueues afterwards
+    OFP_HIP(hipMemcpy(d->d_on_f, onf.data(), C * sizeof(float), hipMemcpyHostToDevice));
+    OFP_HIP(hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice));
+    OFP_HIP(hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice));
+    return OFP_OK;
+}
+
 int ofp_detector_set_tuning(ofp_detector* d, const ofp_detect_tuning* t) {
     OFP_REQUIRE(d && t, "ofp_detector_set_tuning: NULL argument");
     d->t = *t;

@@ -236,6 +236,51 @@ __global__ __launch_bounds__(1024) void k_stream(StreamArgs a) {
     if (threadIdx.x == 0) *a.count = base;
 }
 
+// AmplitudeOnsetDetector.init (detection.py:842-888), the passes over the samples; one lane per
+// channel, rows in order (a one-off calibration over some seconds of audio, not a hot path).
+struct CalArgs {
+    StreamArgs a;
+    int64_t n, r0, r1, n_rev;
+    float* xdb;   // [n][C] scratch: the unclipped rectified dB of the filtered rows
+    float* rel;   // [n][C] out: fast - slow in dB (:862-867)
+};
+
+__global__ __launch_bounds__(64) void k_calibrate(CalArgs q) {
+    const StreamArgs& a = q.a;
+    const int C = a.C;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    StreamState s = carve(a.state, C, a.B, a.btN);
+    float z[4];
+    for (int k = 0; k < 4; ++k) z[k] = s.zi[k * C + c];
+    float yf = s.yf[c], ys = s.ys[c];
+    const float ninf = -__builtin_inff();
+    for (int64_t t = 0; t < q.n; ++t) {                       // :849-852 (no floor clip here)
+        float v = a.x[t * C + c];
+        if (a.hp_on) v = ofp_df2t4_step(v, a.b, a.a, z);
+        q.xdb[t * C + c] = ofp_rect_db(v, ninf);
+    }
+    for (int64_t t = q.r0; t < q.r1; ++t) {                   // :855-860
+        const float v = q.xdb[t * C + c];
+        yf = ofp_ar_step(v, yf, a.fa, a.fr);
+        ys = ofp_ar_step(v, ys, a.sa, a.sr);
+    }
+    for (int64_t t = 0; t < q.n; ++t) {                       // :862-867
+        const float v = q.xdb[t * C + c];
+        yf = ofp_ar_step(v, yf, a.fa, a.fr);
+        ys = ofp_ar_step(v, ys, a.sa, a.sr);
+        q.rel[t * C + c] = yf - ys;
+    }
+    for (int64_t t = q.n_rev - 1; t >= 0; --t) {              // :883-888
+        const float v = q.xdb[t * C + c];
+        yf = ofp_ar_step(v, yf, a.fa, a.fr);
+        ys = ofp_ar_step(v, ys, a.sa, a.sr);
+    }
+    for (int k = 0; k < 4; ++k) s.zi[k * C + c] = z[k];
+    s.yf[c] = yf;
+    s.ys[c] = ys;
+}
+
 StreamArgs make_args(const ofp_detector* d) {
     StreamArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -299,6 +344,26 @@ int ofp_stream_process(ofp_detector* d, void* d_state, const float* d_x, int64_t
     int threads = (int)ofp::align_up(d->p.n_channels, 64);
     hipLaunchKernelGGL(k_stream, dim3(1), dim3(threads), 0, (hipStream_t)stream, a);
     OFP_LAUNCH_CHECK("k_stream");
+    return OFP_OK;
+}
+
+int ofp_stream_calibrate(ofp_detector* d, void* d_state, const float* d_x, int64_t n_rows, int64_t r0, int64_t r1,
+                         int64_t n_rev, float* d_scratch, float* d_rel, void* stream) {
+    OFP_REQUIRE(d && d_state && d_x && d_scratch && d_rel, "ofp_stream_calibrate: NULL argument");
+    OFP_REQUIRE(n_rows >= 1 && 0 <= r0 && r0 <= r1 && r1 <= n_rows && 0 <= n_rev && n_rev <= n_rows,
+                "ofp_stream_calibrate: row ranges outside [0, %lld]", (long long)n_rows);
+    CalArgs q;
+    q.a = make_args(d);
+    q.a.state = d_state;
+    q.a.x = d_x;
+    q.n = n_rows;
+    q.r0 = r0;
+    q.r1 = r1;
+    q.n_rev = n_rev;
+    q.xdb = d_scratch;
+    q.rel = d_rel;
+    hipLaunchKernelGGL(k_calibrate, dim3((unsigned)ofp::cdiv(d->p.n_channels, 64)), dim3(64), 0, (hipStream_t)stream, q);
+    OFP_LAUNCH_CHECK("k_calibrate");
     return OFP_OK;
 }
 

@@ -555,6 +555,51 @@ class AmplitudeOnsetDetector:
         torch.cuda.current_stream(xd.device).synchronize()
 
 
+    def init(self, x):
+        """Initialize the detector with data containing stretches of silence as well as stretches of
+        audio approximately as loud as it will get during performance (detection.py:842-888): sets
+        per-channel `on_threshold` / `off_threshold` (and `mins`, `maxs`, `noise_max`), leaves the
+        filter and follower state where the reference leaves it, prints the reference's message.
+
+        Defined where the reference is: ``len(x)`` and ``sr`` multiples of ``block_size`` (its
+        follower calls always process ``block_size`` rows, detection.py:534-537, and read past the end
+        of a shorter last block), at least one second of audio."""
+        from scipy.ndimage import maximum_filter1d
+
+        x = self._check_block(x)
+        if x.ndim != 2 or x.shape[1] != self.n_signals:
+            raise ValueError(f"expected audio of shape (n, {self.n_signals}), got {x.shape}")
+        n, B, sr = len(x), self.block_size, self.sr
+        starts = range(int(0.1 * sr), int(0.5 * sr), B)
+        r0, r1 = starts[0], starts[-1] + B
+        if n % B or sr % B or r1 > n or n < sr:
+            raise ValueError(
+                f"init: len(x) = {n} and sr = {sr} must be multiples of block_size = {B}, with at least "
+                f"max(sr, {r1}) samples: the reference's follower calls always process block_size rows "
+                "(detection.py:534-537) and read past the end of a shorter last block")
+        dev = self.d.device
+        xd = torch.from_numpy(x).to(dev)
+        scratch = torch.empty_like(xd)
+        rel_d = torch.empty_like(xd)
+        check(self.d.lib.ofp_stream_calibrate(self.d.handle, self._state.data_ptr(), xd.data_ptr(), n, r0, r1, sr,
+                                              scratch.data_ptr(), rel_d.data_ptr(), _stream_ptr(dev)),
+              "ofp_stream_calibrate")
+        rel = rel_d.cpu().numpy()
+        self.mins = np.median(rel[:sr], axis=0)                              # :869-872
+        self.maxs = np.max(rel, axis=0)
+        self.on_threshold = self.maxs * self.on_threshold + self.mins
+        self.off_threshold = self.maxs * self.off_threshold + self.mins
+        self.noise_max = np.median(maximum_filter1d(rel[::], int(sr * 0.01), axis=0), axis=0)
+        noise_thresh = (self.noise_max - self.mins) / self.maxs
+        print("Approx. relative noise thresholds at "
+              f"{[np.round(x, 3) for x in noise_thresh]}!")
+        on = np.ascontiguousarray(np.broadcast_to(np.asarray(self.on_threshold, np.float64), (self.n_signals,)))
+        off = np.ascontiguousarray(np.broadcast_to(np.asarray(self.off_threshold, np.float64), (self.n_signals,)))
+        dp = ctypes.POINTER(ctypes.c_double)
+        check(self.d.lib.ofp_detector_set_thresholds(self.d.handle, on.ctypes.data_as(dp), off.ctypes.data_as(dp)),
+              "ofp_detector_set_thresholds")
+
+
 _FP = ctypes.POINTER(ctypes.c_float)
 
 

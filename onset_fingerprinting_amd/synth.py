@@ -93,3 +93,27 @@ def sensor_hits(seed, n_channels=4, n=24000, hits=12, jitter=12):
 def n_frames(n_samples, n_fft, hop):
     """frames per channel of the dense metric: 1 + (N - F)//B (SURVEY.md 8a a9)."""
     return 0 if n_samples < n_fft else 1 + (n_samples - n_fft) // hop
+
+
+def init_clip(seed, n_channels, sr, seconds, n_follow, amp=1.0):
+    """Calibration recording for AmplitudeOnsetDetector.init (detection.py:842-888): half a second of
+    noise floor, then hits about as loud as it gets; plus `n_follow` samples of further audio for the
+    detector to run on afterwards.  -> (x [seconds*sr, C], y [n_follow, C]) float32."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * sr)
+
+    def make(n, first_hit):
+        a = (1e-3 * rng.standard_normal((n, n_channels))).astype(np.float32)
+        t = np.arange(int(0.05 * sr))
+        pos = first_hit
+        while pos + len(t) < n:
+            for c in range(n_channels):
+                a_hit = amp * (0.3 + 0.6 * rng.random())
+                burst = a_hit * np.exp(-t / (0.004 * sr)) * rng.standard_normal(len(t))
+                o = pos + 13 * c
+                if o + len(t) < n:
+                    a[o:o + len(t), c] += burst.astype(np.float32)
+            pos += int(sr * (0.2 + 0.2 * rng.random()))
+        return a
+
+    return make(n, int(0.7 * sr)), make(n_follow, int(0.05 * sr))

@@ -10,6 +10,7 @@ docstring; reference paths are under ``/root/reference/onset_fingerprinting/``.
 """
 from .detector import (  # noqa: F401
     OracleDetector,
+    init_ranges,
     ar_envelope,
     backtrack_onsets,
     butter_hp_f32,

@@ -59,6 +59,8 @@ lib.oracle_detector_create.restype = ctypes.c_void_p
 lib.oracle_detector_create.argtypes = [ctypes.POINTER(_Params), _f64p, _f64p]
 lib.oracle_detector_destroy.argtypes = [ctypes.c_void_p]
 lib.oracle_detector_warmup.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_long]
+lib.oracle_detector_calibrate.argtypes = [ctypes.c_void_p, _f32p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _f32p]
+lib.oracle_detector_set_thresholds.argtypes = [ctypes.c_void_p, _f64p, _f64p]
 lib.oracle_detector_block.restype = ctypes.c_long
 lib.oracle_detector_block.argtypes = [ctypes.c_void_p, _f32p, _f32p, _i64p, _i64p]
 lib.oracle_detect.restype = ctypes.c_long
@@ -159,6 +161,20 @@ def rel_linear(d, floor):
     return _ew(lib.oracle_rel_linear, d, floor)
 
 
+def init_ranges(n, block_size, sr):
+    """Rows [r0, r1) of the settling blocks of AmplitudeOnsetDetector.init
+    (detection.py:855-860: `range(int(0.1 * sr), int(0.5 * sr), block_size)`), after checking that the
+    reference itself stays inside its buffers for this (n, block_size, sr)."""
+    starts = range(int(0.1 * sr), int(0.5 * sr), block_size)
+    r0, r1 = starts[0], starts[-1] + block_size
+    if n % block_size or sr % block_size or r1 > n or n < sr:
+        raise ValueError(
+            f"init: len(x) = {n} and sr = {sr} must be multiples of block_size = {block_size}, with at least "
+            f"max(sr, {r1}) samples: the reference's follower calls always process block_size rows "
+            "(detection.py:534-537) and read past the end of a shorter last block")
+    return r0, r1
+
+
 class OracleDetector:
     """AmplitudeOnsetDetector (detection.py:595-888) restated; same constructor
     arguments and ``__call__`` contract: x [B][C] float32 ->
@@ -192,6 +208,7 @@ class OracleDetector:
             p.bt_alpha = b_alpha
             p.bt_tol = np.float32((1 - b_alpha) ** backtrack_buffer_size)
         self.params = p
+        self.on_threshold, self.off_threshold = on_threshold, off_threshold
         self.n_signals, self.block_size, self.sr = n_signals, block_size, sr
         self._h = ctypes.c_void_p(lib.oracle_detector_create(ctypes.byref(p), on, off))
         if host_math:  # tests only: the host numpy's log10/power instead of the canon
@@ -205,6 +222,26 @@ class OracleDetector:
     def init_minmax_tracker(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         lib.oracle_detector_warmup(self._h, x, x.shape[0])
+
+    def init(self, x):
+        """detection.py:842-888.  Defined where the reference is: len(x) and sr multiples of the block
+        size (its follower calls always process block_size rows, detection.py:534-537), the settling
+        blocks inside x, at least one second of audio."""
+        from scipy.ndimage import maximum_filter1d
+
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n, B, sr = len(x), self.block_size, self.sr
+        r0, r1 = init_ranges(n, B, sr)
+        rel = np.empty((n, self.n_signals), np.float32)
+        lib.oracle_detector_calibrate(self._h, x, n, r0, r1, sr, rel)
+        self.mins = np.median(rel[:sr], axis=0)
+        self.maxs = np.max(rel, axis=0)
+        self.on_threshold = self.maxs * self.on_threshold + self.mins      # :871-872
+        self.off_threshold = self.maxs * self.off_threshold + self.mins
+        self.noise_max = np.median(maximum_filter1d(rel, int(sr * 0.01), axis=0), axis=0)
+        lib.oracle_detector_set_thresholds(self._h, np.asarray(self.on_threshold, np.float64),
+                                           np.asarray(self.off_threshold, np.float64))
+        return rel
 
     def __call__(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -262,6 +262,52 @@ void oracle_detector_warmup(oracle_detector* d, const float* x, long n) {
     free(xf);
 }
 
+/* init: detection.py:842-888, the passes over the samples.  x is [n][C]; the caller guarantees
+ * that n and every range below are whole blocks (the reference's follower calls always process
+ * block_size rows, detection.py:534-537, so anything else reads past its buffers there).
+ *   high-pass over all rows (:849-850), unclipped rectified dB (:852: no clip here);
+ *   followers over rows [r0, r1) (:855-860: "assumes that first half second is silent");
+ *   followers over all rows, rel_db[n][C] = fast - slow in dB (:862-867);
+ *   followers over rows n_rev-1 .. 0 (:883-888: continuity with the starting point).
+ * The thresholds follow from statistics of rel_db (:869-881) and are set by the caller
+ * (oracle_detector_set_thresholds); tracker and hysteresis state are untouched. */
+void oracle_detector_calibrate(oracle_detector* d, const float* x, long n, long r0, long r1,
+                               long n_rev, float* rel_db) {
+    const oracle_params* p = &d->p;
+    int C = p->C;
+    if (n <= 0) return;
+    float* xf = (float*)malloc((size_t)n * C * sizeof(float));
+    if (p->hp_on) oracle_lfilter4(x, xf, p->b, p->a, d->zi, n, C);
+    else memcpy(xf, x, (size_t)n * C * sizeof(float));
+    d->db_fn(xf, xf, n * C, -INFINITY);
+    for (long t = r0; t < r1; ++t)
+        for (int c = 0; c < C; ++c) {
+            d->yf[c] = ofp_ar_step(xf[t * C + c], d->yf[c], p->fast_att, p->fast_rel);
+            d->ys[c] = ofp_ar_step(xf[t * C + c], d->ys[c], p->slow_att, p->slow_rel);
+        }
+    for (long t = 0; t < n; ++t)
+        for (int c = 0; c < C; ++c) {
+            d->yf[c] = ofp_ar_step(xf[t * C + c], d->yf[c], p->fast_att, p->fast_rel);
+            d->ys[c] = ofp_ar_step(xf[t * C + c], d->ys[c], p->slow_att, p->slow_rel);
+            rel_db[t * C + c] = d->yf[c] - d->ys[c];
+        }
+    for (long t = n_rev - 1; t >= 0; --t)
+        for (int c = 0; c < C; ++c) {
+            d->yf[c] = ofp_ar_step(xf[t * C + c], d->yf[c], p->fast_att, p->fast_rel);
+            d->ys[c] = ofp_ar_step(xf[t * C + c], d->ys[c], p->slow_att, p->slow_rel);
+        }
+    free(xf);
+}
+
+/* self.on_threshold / self.off_threshold replaced by per-channel arrays (detection.py:871-872) */
+void oracle_detector_set_thresholds(oracle_detector* d, const double* on_thr, const double* off_thr) {
+    for (int c = 0; c < d->p.C; ++c) {
+        d->on_f[c] = (float)on_thr[c];
+        d->off_f[c] = (float)off_thr[c];
+        d->on_d[c] = on_thr[c];
+    }
+}
+
 /* __call__: detection.py:727-798.  x [B][C] -> rel [B][C]; channels/deltas
  * (capacity C) ; returns number of onsets in this block. */
 long oracle_detector_block(oracle_detector* d, const float* x, float* rel,

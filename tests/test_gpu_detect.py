@@ -11,6 +11,8 @@ import oracle
 from onset_fingerprinting_amd import synth
 from tests.conftest import load_golden
 from tests.golden.make_golden_cfg import G3_CONFIGS
+from tests.golden.make_golden_init_cfg import G15
+from tests.test_oracle_golden import run_init_case
 
 pytestmark = pytest.mark.gpu
 
@@ -232,3 +234,39 @@ def test_follower_and_filter_classes_match_reference_goldens(det):
     b, a = sig.butter(2, 1500.0, btype="high", fs=48000)
     ref, _ = sig.lfilter(np.float32(b), np.float32(a), g11["x"], axis=0, zi=np.zeros((2, 3), np.float32))
     assert np.array_equal(bits(y2), bits(ref))
+
+
+@pytest.mark.parametrize("name", sorted(G15))
+def test_init_calibration_matches_oracle_and_reference_golden(det, name, capsys):
+    """AmplitudeOnsetDetector.init (detection.py:842-888) on the device: thresholds and the detector's
+    outputs on the audio that follows equal the oracle's bit for bit (same arithmetic canon), and
+    the reference's (g15) within float32 rounding of the thresholds, onsets identical; the message
+    is the reference's."""
+    g, cfg = load_golden("g15_init"), G15[name]
+    d, _, ch, de, blk, rel = run_init_case(
+        lambda C, B, sr, kw: det.AmplitudeOnsetDetector(C, B, sr=sr, **kw), cfg)
+    printed = capsys.readouterr().out
+    o, _, och, ode, oblk, orel = run_init_case(
+        lambda C, B, sr, kw: oracle.OracleDetector(C, B, sr=sr, **kw), cfg)
+    for a, b in ((d.on_threshold, o.on_threshold), (d.off_threshold, o.off_threshold), (d.mins, o.mins),
+                 (d.maxs, o.maxs), (d.noise_max, o.noise_max)):
+        assert np.asarray(a).dtype == np.float32 and np.array_equal(bits(a), bits(b))
+    assert np.array_equal(ch, och) and np.array_equal(de, ode) and np.array_equal(blk, oblk)
+    assert np.array_equal(bits(rel), bits(orel))
+    np.testing.assert_allclose(d.on_threshold, g[f"{name}/on"], rtol=2e-6)
+    np.testing.assert_allclose(d.off_threshold, g[f"{name}/off"], rtol=2e-6)
+    np.testing.assert_allclose(d.noise_max, g[f"{name}/noise_max"], rtol=2e-6)
+    assert np.array_equal(ch, g[f"{name}/ch"]) and np.array_equal(de, g[f"{name}/delta"])
+    assert np.array_equal(blk, g[f"{name}/block"])
+    np.testing.assert_allclose(rel[::31], g[f"{name}/rel_stride"], rtol=2e-5, atol=1e-7)
+    assert printed.startswith("Approx. relative noise thresholds at [") and printed.rstrip().endswith("]!")
+    if name == "manual_48k_64":
+        assert len(ch) > 0
+
+
+def test_init_is_refused_where_the_reference_reads_past_its_buffers(det):
+    d = det.AmplitudeOnsetDetector(2, 256, sr=48000)  # 48000 is not a multiple of 256
+    with pytest.raises(ValueError, match="multiples of block_size"):
+        d.init(np.zeros((48000 * 2 // 256 * 256, 2), np.float32))
+    with pytest.raises(ctypes.ArgumentError):
+        det.AmplitudeOnsetDetector(2, 128, sr=48000).init(np.zeros((96000, 2), np.float64))

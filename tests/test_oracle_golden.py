@@ -9,6 +9,7 @@ import oracle
 from tests.conftest import load_golden
 from onset_fingerprinting_amd import synth
 from tests.golden.make_golden_cfg import G3_CONFIGS
+from tests.golden.make_golden_init_cfg import G15
 
 
 def ulp_diff(a, b):
@@ -221,3 +222,57 @@ def test_g8_models():
         sd = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/") and k.split("/")[1] not in ("x", "y")}
         y = oracle.cnn_forward(sd, g[f"{name}/x"], **kw)
         np.testing.assert_allclose(y, g[f"{name}/y"], rtol=1e-4, atol=1e-5)
+
+
+def run_init_case(make_detector, cfg):
+    """init(x) on the calibration clip, then the detector over the audio that follows."""
+    sr, B, C = cfg["sr"], cfg["B"], cfg["C"]
+    x, y = synth.init_clip(cfg["seed"], C, sr, cfg["seconds"], cfg["follow_blocks"] * B, amp=cfg.get("amp", 1.0))
+    d = make_detector(C, B, sr, cfg["kw"])
+    d.init(x)
+    ch, de, blk, rel = [], [], [], []
+    for j in range(cfg["follow_blocks"]):
+        c, dl, r = d(y[j * B:(j + 1) * B])
+        ch += list(c)
+        de += list(dl)
+        blk += [j] * len(c)
+        rel.append(np.array(r, copy=True))
+    return d, (x, y), np.array(ch, np.int64), np.array(de, np.int64), np.array(blk, np.int64), np.concatenate(rel)
+
+
+@pytest.mark.parametrize("host_math", [True, False])
+@pytest.mark.parametrize("name", sorted(G15))
+def test_g15_init_thresholds_and_the_state_it_leaves(name, host_math):
+    """AmplitudeOnsetDetector.init (detection.py:842-888): thresholds, mins/maxs/noise_max and the
+    per-block outputs AFTER init against the reference; bit-for-bit with the host's numpy log10/power,
+    within float32 rounding of the thresholds with the arithmetic canon (onsets identical)."""
+    if host_math and not host_math_matches():
+        pytest.skip("host numpy float32 log10/power differ from the capture machine")
+    g, cfg = load_golden("g15_init"), G15[name]
+    d, (x, y), ch, de, blk, rel = run_init_case(
+        lambda C, B, sr, kw: oracle.OracleDetector(C, B, sr=sr, host_math=host_math, **kw), cfg)
+    assert [x.astype(np.float64).sum(), y.astype(np.float64).sum()] == list(g[f"{name}/xsum"]), "generator drifted"
+    for key, val in (("on", d.on_threshold), ("off", d.off_threshold), ("mins", d.mins), ("maxs", d.maxs),
+                     ("noise_max", d.noise_max)):
+        want = g[f"{name}/{key}"]
+        assert np.asarray(val).dtype == want.dtype == np.float32
+        if host_math:
+            assert np.array_equal(np.asarray(val), want), key
+        else:
+            np.testing.assert_allclose(val, want, rtol=2e-6, err_msg=key)
+    assert np.array_equal(ch, g[f"{name}/ch"]) and np.array_equal(de, g[f"{name}/delta"])
+    assert np.array_equal(blk, g[f"{name}/block"])
+    if host_math:
+        assert np.array_equal(rel[::31], g[f"{name}/rel_stride"])
+    else:
+        np.testing.assert_allclose(rel[::31], g[f"{name}/rel_stride"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(rel.astype(np.float64).sum(0), g[f"{name}/rel_sum"], rtol=1e-5)
+
+
+def test_init_is_refused_where_the_reference_reads_past_its_buffers():
+    d = oracle.OracleDetector(2, 256, sr=48000)  # 48000 is not a multiple of 256
+    with pytest.raises(ValueError, match="multiples of block_size"):
+        d.init(np.zeros((48000 * 2 // 256 * 256, 2), np.float32))
+    d = oracle.OracleDetector(2, 128, sr=48000)
+    with pytest.raises(ValueError):
+        d.init(np.zeros((128 * 100, 2), np.float32))  # shorter than the settling blocks / one second
