@@ -25,8 +25,14 @@ def _stream(dev):
 
 
 def _device(device=0):
-    _lib.require_gpu(int(device) if not isinstance(device, torch.device) else (device.index or 0))
-    return device if isinstance(device, torch.device) else torch.device("cuda", int(device))
+    if isinstance(device, str):
+        device = torch.device(device)
+    if isinstance(device, torch.device):
+        if device.type != "cuda":
+            raise _lib.OnsetFPError(f"this library computes on an MI355X only (device {device} requested)")
+        device = device.index or 0
+    _lib.require_gpu(int(device))
+    return torch.device("cuda", int(device))
 
 
 def _pad_center(data, size):
@@ -335,4 +341,45 @@ class FrameExtractor:
         return out if a.ndim == 2 else out[:, 0, :]
 
 
-FastFrameExtractor = FrameExtractor  # data.py:123-192 is the torch twin of the same gather
+class FastFrameExtractor:
+    """data.py:123-192: holds the audio (in HBM) and the onsets, always starts a frame at the minimum
+    onset of its group, and returns a torch tensor ``[O, C, W]`` (``[O, W]`` for 1-D audio) from
+    ``__call__()``.  ``device=None`` returns CPU tensors and draws the random shifts from torch's CPU
+    generator, exactly as the reference does; any other device keeps the frames on that GPU.
+    Frames that would start before the audio or end after it raise ``IndexError`` (the reference's
+    ``audio.unfold(...)[index]`` wraps negative indices around silently)."""
+
+    def __init__(self, audio: np.ndarray, onsets: np.ndarray, frame_length: int, pre_samples: int,
+                 max_shift: int = 0, add_pre_samples: bool = False, device=None):
+        self.device = device
+        self.frame_length = frame_length
+        self.pre_samples = pre_samples
+        if add_pre_samples:
+            self.frame_length += self.pre_samples
+        self.max_shift = max_shift
+        self._gpu = _device(0 if device is None else device)
+        onsets = np.asarray(onsets, dtype=np.int64)
+        self._onsets = onsets.min(1) if onsets.ndim == 2 else onsets
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        self._one_d = a.ndim == 1
+        self._x = torch.from_numpy(a[:, None] if self._one_d else a).to(self._gpu).contiguous()
+        self._gather = FrameExtractor(self.frame_length, 0, device=self._gpu)
+        if self.max_shift > 0:
+            self.onsets = torch.as_tensor(self._onsets, device=device)
+        else:
+            self.frames = self._frames(self._onsets - self.pre_samples)
+
+    def _frames(self, starts):
+        starts = np.asarray(starts, dtype=np.int64)
+        N, C = self._x.shape
+        if starts.min(initial=0) < 0 or starts.max(initial=0) + self.frame_length > N:
+            raise IndexError("frame outside the audio array")
+        out = self._gather.extract_device(self._x, np.repeat(starts[:, None], C, axis=1))
+        out = out[:, 0, :] if self._one_d else out
+        return out.cpu() if self.device is None else out
+
+    def __call__(self):
+        if self.max_shift:
+            shifts = torch.randint(-self.max_shift, self.max_shift + 1, (len(self._onsets),), device=self.device)
+            return self._frames(self._onsets - (self.pre_samples - shifts.cpu().numpy()))
+        return self.frames

@@ -6,6 +6,7 @@ import ast
 
 import numpy as np
 import pytest
+import torch
 
 import oracle
 from tests.conftest import load_golden
@@ -111,6 +112,28 @@ def test_g7_frame_extractor_exact(data):
     assert np.array_equal(data.FrameExtractor(64, 8)(a[:, 0].copy(), o[:, 0]), g["f1d"])
     with pytest.raises(IndexError):
         data.FrameExtractor(256, 16)(a, np.array([[4900, 4900, 4900, 4900]]))
+
+
+def test_g16_fast_frame_extractor_exact(data):
+    """data.FastFrameExtractor (data.py:123-192) against the reference's outputs: 1-D / 2-D audio and
+    onsets, add_pre_samples, and random shifts drawn from torch's CPU generator under the same seeds."""
+    from tests.golden.make_golden_init_cfg import G16, g16_inputs
+    g = load_golden("g16_fastframes")
+    for name, cfg in G16.items():
+        audio, onsets = g16_inputs(cfg)
+        torch.manual_seed(cfg["seed"])
+        fe = data.FastFrameExtractor(audio, onsets, **cfg["kw"])
+        for call in range(2):
+            torch.manual_seed(cfg["seed"] + 1 + call)
+            got = fe()
+            assert isinstance(got, torch.Tensor) and got.dtype == torch.float32 and got.device.type == "cpu"
+            assert np.array_equal(got.numpy(), g[f"{name}/call{call}"]), (name, call)
+    # device given: the frames stay in HBM
+    audio, onsets = g16_inputs(G16["2d_min_onset"])
+    fe = data.FastFrameExtractor(audio, onsets, device="cuda", **G16["2d_min_onset"]["kw"])
+    assert fe().device.type == "cuda" and np.array_equal(fe().cpu().numpy(), g["2d_min_onset/call0"])
+    with pytest.raises(IndexError):
+        data.FastFrameExtractor(audio, np.array([[5990, 5990, 5990, 5990]]), 64, 8)
 
 
 def test_mel_and_mfcc_match_oracle(data):
