@@ -78,6 +78,20 @@ __device__ __forceinline__ void dftR(float2* v) {
 // inputs of all its butterflies into registers, a workgroup barrier separates the reads from the
 // writes, so the autosort permutation needs no second buffer (half the LDS per frame, more
 // workgroups per CU).  Ns = product of the radices already done.
+// Barrier between the lanes that share one frame.  Up to 64 lanes per frame, a frame lives inside
+// one wave: its LDS instructions execute in order, so nothing has to wait for the other waves of the
+// workgroup (which work on other frames) -- only the compiler must not move accesses across.
+template <int T>
+__device__ __forceinline__ void frame_sync() {
+    if constexpr (T <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int R, int M, int T>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
     constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
@@ -89,7 +103,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
 #pragma unroll
         for (int i = 0; i < R; ++i) v[b][i] = buf[j + i * (M / R)];
     }
-    __syncthreads();  // all reads of this pass are done
+    frame_sync<T>();  // all reads of this pass are done
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
@@ -102,7 +116,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
 #pragma unroll
         for (int i = 0; i < R; ++i) buf[j0 + i * Ns] = v[b][i];
     }
-    __syncthreads();  // all writes are visible to the next pass
+    frame_sync<T>();  // all writes are visible to the next pass
 }
 
 template <int M> struct Radices;
@@ -118,7 +132,7 @@ template <int M, int T>
 __device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
     using Rx = Radices<M>;
     int Ns = 1;
-    __syncthreads();  // the frame has been written
+    frame_sync<T>();  // the frame has been written
 #pragma unroll
     for (int p = 0; p < Rx::n; ++p) {
         if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
@@ -241,10 +255,11 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         }
     };
     fetch(blockIdx.x);
+    __syncthreads();  // tables ready
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
         const bool valid = f < total_frames;
-        __syncthreads();  // tables ready / previous iteration's reads done
+        frame_sync<T>();  // previous iteration's reads of this frame's buffer are done
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = tid + q * T;
@@ -270,12 +285,12 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
                 if (tid + q * T <= M) dst[tid + q * T] = pk[q];
         }
         if (mf.mel) {
-            __syncthreads();  // every bin of the spectrum has been read
+            frame_sync<T>();  // every bin of the spectrum has been read
             float* pf = reinterpret_cast<float*>(A);
 #pragma unroll
             for (int q = 0; q < NK; ++q)
                 if (tid + q * T <= M) pf[tid + q * T] = pk[q];
-            __syncthreads();
+            frame_sync<T>();
             if (valid) {
                 for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
                     const float* p = pf + flo[b];
