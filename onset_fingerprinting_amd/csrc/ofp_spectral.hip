@@ -109,8 +109,10 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
         const int j = tid + b * T;
         const int k = j & (Ns - 1);
         const int tstep = k * (M / (Ns * R));
+        if (Ns > 1) {  // the first pass has k = 0: every twiddle is 1
 #pragma unroll
-        for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
+            for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
+        }
         dftR<R>(v[b]);
         const int j0 = (j - k) * R + k;
 #pragma unroll
