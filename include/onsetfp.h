@@ -210,11 +210,13 @@ int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t
 int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels, int32_t n_fft,
                        int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
                        const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
-                       float* d_mel, int32_t planar_input, void* stream);
-/* planar_input != 0: d_x is [n_clips][C][n_samples] (one series per channel), e.g. the transposed
- * copy the detector keeps in its work space between ofp_detect_offline_begin and the next begin: */
+                       float* d_mel, int64_t planar_stride, void* stream);
+/* planar_stride != 0: d_x points at one series per (clip, channel), planar_stride floats apart, e.g.
+ * the planar copy the detector keeps in its work space between ofp_detect_offline_begin and the next
+ * begin (each series there is preceded by the warm-up part of the detector's stream): */
 const float* ofp_detect_planar_input(const ofp_detector* det, int64_t n_clips, int64_t n_samples, int64_t warm,
                                      const void* d_ws);
+int64_t ofp_detect_planar_stride(const ofp_detector* det, int64_t n_clips, int64_t n_samples, int64_t warm);
 
 /* Gathered complex STFT frames (data.py:593-654 semantics are built on this by
  * the Python layer): for each of n_frames (clip, channel, start) triples,

@@ -90,8 +90,9 @@ SIGNATURES = {
     "ofp_detector_set_thresholds": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ofp_stft_power": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "ofp_stft_power_mel": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
-                                          _i32, _vp]),
+                                          _i64, _vp]),
     "ofp_detect_planar_input": (_vp, [_vp, _i64, _i64, _i64, _vp]),
+    "ofp_detect_planar_stride": (_i64, [_vp, _i64, _i64, _i64]),
     "ofp_stft_frames": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                        _vp, _vp, _vp]),
     "ofp_extract_frames": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),

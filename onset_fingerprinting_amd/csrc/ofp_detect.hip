@@ -65,6 +65,7 @@ struct Geom {
     int64_t n_wb;  // warm samples through followers/tracker: full blocks only (:832-834)
     int64_t U;     // follower stream length n_wb + Nm
     int64_t V;     // high-pass stream length n_w + Nm
+    int64_t Nv;    // floats per series of the planar input copy: x[0:n_w] ++ x[0:N] (rounded up to 4)
     int32_t C, B;
 };
 // The reference processes x[0:n_w] (init_minmax_tracker) and then restarts at x[0] with all
@@ -74,6 +75,12 @@ __host__ __device__ inline int64_t hp_dst(const Geom& g, int64_t v) {
     return v < g.n_wb ? v : (v >= g.n_w ? v - g.n_w + g.n_wb : -1);
 }
 __host__ __device__ inline int64_t u_src(const Geom& g, int64_t u) { return u < g.n_wb ? u : u - g.n_wb; }
+// The planar copy of the input holds the high-pass stream itself, x[0:n_w] ++ x[0:N], contiguous per
+// series: a lane that walks the stream walks memory, whatever side of the restart it is on (with the
+// restart as a jump in the source, the lanes of a wave that cross it at different steps serialised:
+// the waves holding chunks 3-9 of every series ran 1.6 x longer than all others and set the launch's
+// duration).  Follower-stream index u -> index in that copy:
+__host__ __device__ inline int64_t u_src_planar(const Geom& g, int64_t u) { return u < g.n_wb ? u : u - g.n_wb + g.n_w; }
 
 // ---------------------------------------------------------------------------
 // walk: the one inner loop.  A lane walks n consecutive floats of ITS OWN series,
@@ -301,7 +308,7 @@ struct MaxStepEv {
 // ---------------------------------------------------------------------------
 // k_transpose_in: caller audio [clip][N][C] -> planar [clip][C][N]
 __global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
-                                                      int64_t N, int C, int TU) {
+                                                      int64_t N, int C, int TU, int64_t n_w, int64_t Nv) {
     extern __shared__ float tile[];  // [C][TU+1]
     const int64_t clip = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * TU;
@@ -315,7 +322,10 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ 
     __syncthreads();
     for (int i = threadIdx.x; i < total; i += 256) {
         const int c = i / nt, t = i - c * nt;
-        xt[(clip * C + c) * N + t0 + t] = tile[c * (TU + 1) + t];
+        float* row = xt + (clip * C + c) * Nv;
+        const float v = tile[c * (TU + 1) + t];
+        row[n_w + t0 + t] = v;
+        if (t0 + t < n_w) row[t0 + t] = v;  // the warm-up part of the stream (detection.py:70)
     }
 }
 
@@ -650,18 +660,22 @@ struct HpArgs {
 // breaks n_wb and n_w (detection.py:828-834: the tail of the warm-up passes the filter only)
 template <bool OUT, class F>
 __device__ __forceinline__ void hp_span(const HpArgs& a, F& f, int64_t chain, int64_t t0, int64_t t1) {
-    const float* xs = a.xt + chain * a.g.N;
+    const float* xs = a.xt + chain * a.g.Nv;  // the stream itself (see u_src_planar)
+    int norem = -1;
+    if (!OUT) {
+        if (t1 > t0) walk<8, 0, false>(xs + t0, nullptr, t1 - t0, norem, f);
+        return;
+    }
     float* os = a.out + chain * a.g.U;
     int64_t p = t0;
-    int norem = -1;
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {  // the OUTPUT has the breaks: rows n_wb..n_w pass the filter only
         const int64_t br = i == 0 ? a.g.n_wb : (i == 1 ? a.g.n_w : t1);
         const int64_t e = min(max(br, p), t1);
         if (e > p) {
             const int64_t u = hp_dst(a.g, p);
-            if (OUT && u >= 0) walk<8, 1, false>(xs + hp_src(a.g, p), os + u, e - p, norem, f);
-            else walk<8, 0, false>(xs + hp_src(a.g, p), nullptr, e - p, norem, f);
+            if (u >= 0) walk<8, 1, false>(xs + p, os + u, e - p, norem, f);
+            else walk<8, 0, false>(xs + p, nullptr, e - p, norem, f);
         }
         p = e;
     }
@@ -690,6 +704,7 @@ struct HpCand {
     int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
                       // unverified guesses
     int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
+    unsigned long long* probe;  // diagnostics (OFP_HP_PROBE): per wave {start, end (s_memtime), HW_ID, XCC_ID}; else NULL
     __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
         return ((((clip * st.n_chunks + k) * st.g.C + c) * (R + 1)) + r) * 4;
     }
@@ -713,6 +728,8 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
         if (n_threads < 0) claim[threadIdx.x] = 1;  // never taken: keeps the allocation alive
     }
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long t_probe = 0;
+    if (a.probe) t_probe = __builtin_amdgcn_s_memtime();
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
     // One lane = one RUN: it warms up over W samples before chunk j and then walks through `span`
@@ -776,6 +793,13 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
 #pragma unroll
             for (int w = 0; w < 4; ++w) dst[w] = ofp_f2u(s.z[w]);
         }
+    }
+    if (a.probe && (threadIdx.x & 63) == 0) {
+        unsigned long long* q = a.probe + 4 * (id >> 6);
+        q[0] = t_probe;
+        q[1] = __builtin_amdgcn_s_memtime();
+        q[2] = (unsigned)__builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID: wave, simd, cu, sh, se ...
+        q[3] = (unsigned)__builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
     }
 }
 
@@ -1069,7 +1093,7 @@ __global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict
         float v;
         if (from_x) {
             const int64_t chain = i / g.U, u = i - chain * g.U;
-            v = xt[chain * g.N + u_src(g, u)];
+            v = xt[chain * g.Nv + u_src_planar(g, u)];
         } else {
             v = buf[i];
         }
@@ -1488,6 +1512,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     g.n_wb = (g.n_w / g.B) * g.B;
     g.U = g.n_wb + g.Nm;
     g.V = g.n_w + g.Nm;
+    g.Nv = align_up(g.n_w + N, 4);
     l.nb = g.Nm / g.B;
     // longest follower time constant in samples (coefficient = 1/samples)
     const float cmin = std::min(std::min(p.fast_attack, p.fast_release), std::min(p.slow_attack, p.slow_release));
@@ -1544,7 +1569,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         o += align_up(bytes, 256);
         return r;
     };
-    l.o_xt = take(n_clips * g.C * N * 4 + 64);
+    l.o_xt = take(n_clips * g.C * g.Nv * 4 + 64);
     l.o_xdb = take(n_clips * g.C * g.U * 4 + 64);
     l.o_dif = take(n_clips * g.C * g.U * 4 + 64);
     {
@@ -1743,7 +1768,13 @@ int ofp_detector_set_tuning(ofp_detector* d, const ofp_detect_tuning* t) {
 const float* ofp_detect_planar_input(const ofp_detector* d, int64_t n_clips, int64_t n_samples, int64_t warm,
                                      const void* d_ws) {
     if (!d || !d_ws || n_clips < 1 || n_samples < 0) return nullptr;
-    return reinterpret_cast<const float*>(static_cast<const char*>(d_ws) + make_layout(d, n_clips, n_samples, warm).o_xt);
+    const Layout l = make_layout(d, n_clips, n_samples, warm);
+    return reinterpret_cast<const float*>(static_cast<const char*>(d_ws) + l.o_xt) + l.g.n_w;
+}
+
+int64_t ofp_detect_planar_stride(const ofp_detector* d, int64_t n_clips, int64_t n_samples, int64_t warm) {
+    if (!d || n_clips < 1 || n_samples < 0) return -1;
+    return make_layout(d, n_clips, n_samples, warm).g.Nv;
 }
 
 int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64_t n_samples,
@@ -1794,7 +1825,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     if (phase != 2) {
         OFP_HIP(hipMemsetAsync(ws + l.o_zero, 0, (size_t)l.zero_bytes, stream));  // counters, flags: see make_layout
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
-                           stream, d_x, xt, N, g.C, l.tu);
+                           stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
         OFP_LAUNCH_CHECK("k_transpose_in");
         OFP_HIP(hipEventRecord(ev[8], stream));
     }
@@ -1825,6 +1856,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.gs = reinterpret_cast<int8_t*>(ws + l.o_hp_gs);
         hc.counters = ctr.base;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
+        hc.probe = nullptr;
+        const char* probe_path = phase != 2 ? getenv("OFP_HP_PROBE") : nullptr;
+        const int64_t probe_waves = cdiv(chains * l.hp_chunks * (l.hp_R / l.hp_span), 64);
+        if (probe_path) OFP_HIP(hipMalloc(&hc.probe, probe_waves * 32));
         const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
@@ -1837,6 +1872,18 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 hipLaunchKernelGGL(k_hp_candidates<false>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
             OFP_LAUNCH_CHECK("k_hp_candidates");
             OFP_HIP(hipEventRecord(ev[7], stream));
+            if (hc.probe) {  // diagnostics: where and when every wave of the launch ran (tools/wave_placement.py)
+                std::vector<unsigned long long> h(probe_waves * 4);
+                OFP_HIP(hipStreamSynchronize(stream));
+                OFP_HIP(hipMemcpy(h.data(), hc.probe, probe_waves * 32, hipMemcpyDeviceToHost));
+                (void)hipFree(hc.probe);
+                hc.probe = nullptr;
+                if (FILE* f = fopen(probe_path, "w")) {
+                    for (int64_t w = 0; w < probe_waves; ++w)
+                        fprintf(f, "%lld %llu %llu %llu %llu\n", (long long)w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+                    fclose(f);
+                }
+            }
         }
         hp_cand_timed = true;
         {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)

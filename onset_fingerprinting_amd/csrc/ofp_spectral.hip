@@ -204,7 +204,7 @@ struct MelFuse {
 template <int F>
 __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
-                                                            float* __restrict__ power, MelFuse mf, int planar) {
+                                                            float* __restrict__ power, MelFuse mf, int64_t planar) {
     using G = Cfg<F>;
     constexpr int M = G::M, T = G::T, FPW = G::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             const int64_t clip = cc / C;
             // interleaved [clip][time][C] (the caller's layout: a lane's two samples sit in two 32-B
             // sectors of which it uses 4 B) or planar [clip][C][time] (consecutive lanes, consecutive
-            // floats: the detector's transposed copy, 8x less L2 traffic at C = 8)
+            // floats: the detector's transposed copy, 8x less L2 traffic at C = 8; `planar` = floats between series)
             const int64_t stride = planar ? 1 : C;
-            const float* src = planar ? x + cc * n_samples + h * hop : x + (clip * n_samples + h * hop) * C + c;
+            const float* src = planar ? x + cc * planar + h * hop : x + (clip * n_samples + h * hop) * C + c;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const int n = tid + q * T;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
 
 template <int F>
 int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
-                 const MelFuse& mf, int planar, hipStream_t stream) {
+                 const MelFuse& mf, int64_t planar, hipStream_t stream) {
     using G = Cfg<F>;
     size_t lds = G::lds_bytes;
     if (mf.mel) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
@@ -475,7 +475,7 @@ int launch_frames(const FrameArgs& a, hipStream_t stream) {
 extern "C" {
 
 static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
-                           int32_t hop, float* d_power, const MelFuse& mf, int planar, void* stream_) {
+                           int32_t hop, float* d_power, const MelFuse& mf, int64_t planar, void* stream_) {
     OFP_REQUIRE(d_x && (d_power || mf.mel), "ofp_stft_power: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && C >= 1 && hop >= 1, "ofp_stft_power: bad sizes");
     if (n_samples < n_fft) return OFP_OK;  // no complete frame
@@ -500,13 +500,13 @@ int ofp_stft_power(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t
 int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
                        int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
                        const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
-                       float* d_mel, int32_t planar_input, void* stream) {
+                       float* d_mel, int64_t planar_stride, void* stream) {
     OFP_REQUIRE(d_fb_lo && d_fb_len && d_fb_off && d_fb_w && d_mel && n_mels >= 1 && fb_nnz >= 1,
                 "ofp_stft_power_mel: NULL / empty filterbank");
     OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel: filterbank with %d weights for %d bins", fb_nnz,
                 n_fft / 2 + 1);
     MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel};
-    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_input ? 1 : 0, stream);
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream);
 }
 
 int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, const int32_t* d_clip,

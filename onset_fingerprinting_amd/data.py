@@ -95,7 +95,7 @@ def stft_power_dense(x, n_fft, hop, out=None):
     return out
 
 
-def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, want_power=True, planar_ptr=None):
+def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, want_power=True, planar=None):
     """`stft_power_dense` and `melbank(power)` in one kernel: the filterbank is applied while each
     frame's power spectrum is still in LDS.  Returns (power or None, mel [n_clips, C, H, n_mels])."""
     if n_fft not in SUPPORTED_NFFT:
@@ -108,12 +108,13 @@ def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, w
     if out_mel is None:
         out_mel = torch.empty((n_clips, C, H, melbank.n_mels), dtype=torch.float32, device=x.device)
     if H:
-        # planar_ptr: device address of the same audio as [n_clips][C][N] (BatchDetector.planar_input)
-        check(L.ofp_stft_power_mel(planar_ptr if planar_ptr else x.data_ptr(), n_clips, N, C, n_fft, hop,
+        # planar: (device address, stride) of the same audio as one series per clip and channel
+        # (BatchDetector.planar_input)
+        check(L.ofp_stft_power_mel(planar[0] if planar else x.data_ptr(), n_clips, N, C, n_fft, hop,
                                    out_power.data_ptr() if want_power else None, melbank.n_mels,
                                    melbank.lo.data_ptr(), melbank.len.data_ptr(), melbank.off.data_ptr(),
                                    melbank.w.data_ptr(), melbank.w.numel(), out_mel.data_ptr(),
-                                   1 if planar_ptr else 0, _stream(x.device)),
+                                   planar[1] if planar else 0, _stream(x.device)),
               "ofp_stft_power_mel")
     return (out_power if want_power else None), out_mel
 

@@ -140,14 +140,16 @@ class BatchDetector:
                                                   ws.numel(), _stream_ptr(x.device)), "ofp_detect_offline_begin")
 
     def planar_input(self, x, warm=None):
-        """Device address of the transposed copy [n_clips][C][N] of `x` that `begin` (or `detect`)
-        left in the work space; valid until the next begin/detect on this detector."""
+        """(device address, stride in floats) of the planar copy of `x` (one series per clip and
+        channel, `stride` floats apart) that `begin` (or `detect`) left in the work space; valid
+        until the next begin/detect on this detector."""
         if x.dim() == 2:
             x = x.unsqueeze(0)
         n_clips, N, C = x.shape
         warm = int(0.5 * self.sr) if warm is None else int(warm)
         ws = self.reserve(n_clips, N, warm)
-        return self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr())
+        return (self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr()),
+                int(self.d.lib.ofp_detect_planar_stride(self.d.handle, n_clips, N, warm)))
 
     def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
         """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of

@@ -95,7 +95,7 @@ class FingerprintPipeline:
             # the frame's power spectrum is still in LDS)
             # (it reads the transposed copy of x the detector's head just made: coalesced loads)
             power, mel = stft_power_mel_dense(x, self.n_fft, self.hop, self.mel, out_power=b["power"],
-                                              out_mel=b["mel"], planar_ptr=self.detector.planar_input(x))
+                                              out_mel=b["mel"], planar=self.detector.planar_input(x))
             self._ev[1].record(side)
             self._ev[2].record(side)
             logits = self.classifier(mel.reshape(-1, self.n_mels))

@@ -178,5 +178,10 @@ def test_fused_stft_mel_equals_the_two_kernels():
         p2, m2 = data.stft_power_mel_dense(x, n_fft, hop, mb, want_power=False)
         assert p2 is None and torch.equal(m0, m2)
         xt = x.transpose(1, 2).contiguous()  # planar [clip][C][N]: same values, coalesced loads
-        p3, m3 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar_ptr=xt.data_ptr())
+        p3, m3 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar=(xt.data_ptr(), N))
         assert torch.equal(p0, p3) and torch.equal(m0, m3)
+        # series further apart than their length (the detector's copy has the warm-up in between)
+        xw = torch.zeros((2, C, N + 1000), dtype=torch.float32, device="cuda")
+        xw[:, :, 1000:] = xt
+        p4, m4 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar=(xw.data_ptr() + 4000, N + 1000))
+        assert torch.equal(p0, p4) and torch.equal(m0, m4)
