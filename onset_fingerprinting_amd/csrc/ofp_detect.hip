@@ -214,6 +214,16 @@ struct ArStep {
     __device__ void event() {}
 };
 
+// one follower alone (the two do not involve each other): half the instructions of ArStep per step
+struct ArOne {
+    float y, att, rel;
+    __device__ float operator()(float xv) {
+        y = ofp_ar_step(xv, y, att, rel);
+        return 0.0f;
+    }
+    __device__ void event() {}
+};
+
 // the same followers in plain fp32 fma arithmetic: only a GUESS generator for the exact warm-up
 struct ArCoarse {
     float yf, ys, fa, fr, sa, sr;
@@ -336,7 +346,7 @@ struct ArArgs {
     const float* xdb;  // planar [clip*C + c][U]
     float* dif;        // planar
     float fa, fr, sa, sr, floor_db;
-    int64_t L, W, Wc, n_chunks;
+    int64_t L, W, Wc, Wf, n_chunks;
 };
 
 // The stage is split into LEAN kernels, one walk instantiation each: measured on gfx950, the
@@ -461,6 +471,35 @@ __global__ __launch_bounds__(64) void k_ar_warm(ArArgs a, int64_t n_threads, uin
     walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
     used[sidx] = ofp_f2u(s.yf);
     used[sidx + 1] = ofp_f2u(s.ys);
+}
+
+// The same warm-up with the followers as separate lanes (symmetric-guess path): the slow one walks
+// its whole window from the closed-form guess (first half of the grid) WHILE the fast one, which
+// starts from the floor and forgets it within ~24 of its own time constants, walks the last Wf
+// samples only (second half), each with half the instructions per step.
+__global__ __launch_bounds__(64) void k_ar_warm2(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t half = (n_threads + 63) / 64;
+    const bool fast = blockIdx.x >= half;
+    const int64_t id = ((int64_t)blockIdx.x - (fast ? half : 0)) * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const float* xs = a.xdb + chain * a.g.U;
+    int norem = -1;
+    if (!fast) {
+        const int64_t ws = max<int64_t>(start - a.W, 0);
+        ArOne s{ofp_u2f(used[sidx + 1]), a.sa, a.sr};
+        walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
+        used[sidx + 1] = ofp_f2u(s.y);
+    } else {
+        const int64_t ws = max<int64_t>(start - min(a.W, a.Wf), 0);
+        ArOne s{a.floor_db, a.fa, a.fr};  // the true state at sample 0 (:697-702), a guess elsewhere
+        walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
+        used[sidx] = ofp_f2u(s.y);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_threads,
@@ -1488,7 +1527,7 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R, hp_S, hp_span;
-    int64_t ar_L, ar_W, ar_Wc, ar_chunks;
+    int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks;
     int tu;  // time steps per transpose tile
@@ -1542,6 +1581,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.ar_L = pick(d->t.ar_chunk, arL);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
     l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
+    l.ar_Wf = l.ar_W;
     // symmetric slow follower: closed-form guess (k_ar_sym_local/combine) instead of the
     // sequential approximate pass.  The guess is good to ~10 ulps (it ignores the fp32 roundings
     // of the real trajectory) and a difference of a few ulps dies out like exp(-t/tau) only, so
@@ -1555,6 +1595,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         const double tau_s = 1.0 / p.slow_attack, tau_f = cf > 0 ? 1.0 / cf : 1.0;
         l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(std::max(11.0 * tau_s, 24.0 * tau_f), 4.0e6), 1024));
         l.ar_W = align_up(l.ar_W, l.ar_L);  // the guess is available at chunk boundaries
+        l.ar_Wf = align_up((int64_t)std::min(24.0 * tau_f, 4.0e6), 1024);  // the fast follower's own window
         l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(16.0 * tau_s, 8.0e6), 1024));
     }
     l.mm_L = pick(d->t.mm_chunk, mmL);
@@ -1939,6 +1980,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.L = l.ar_L;
         a.W = l.ar_W;
         a.Wc = l.ar_Wc;
+        a.Wf = l.ar_Wf;
         a.n_chunks = l.ar_chunks;
         const int64_t nt = chains * l.ar_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
@@ -1954,8 +1996,13 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             hipLaunchKernelGGL(k_ar_coarse, dim3(grid), dim3(64), 0, stream, a, nt, used);
             OFP_LAUNCH_CHECK("k_ar_coarse");
         }
-        hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
-        OFP_LAUNCH_CHECK("k_ar_warm");
+        if (l.ar_sym) {
+            hipLaunchKernelGGL(k_ar_warm2, dim3(2 * grid), dim3(64), 0, stream, a, nt, used);
+            OFP_LAUNCH_CHECK("k_ar_warm2");
+        } else {
+            hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
+            OFP_LAUNCH_CHECK("k_ar_warm");
+        }
         int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
                             stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
