@@ -167,6 +167,12 @@ int ofp_detect_offline_finish(ofp_detector* det, const float* d_x, int64_t n_cli
                               int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
                               int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream);
 
+/* _begin in two calls: _begin_input enqueues the planar copy of the input only (ofp_detect_planar_input
+ * is valid once it has run), _begin_iir the IIR candidate launch. */
+int ofp_detect_offline_begin_input(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                                   int64_t warm, void* d_ws, int64_t ws_bytes, void* stream);
+int ofp_detect_offline_begin_iir(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                                 int64_t warm, void* d_ws, int64_t ws_bytes, void* stream);
 /* Streaming form: AmplitudeOnsetDetector.__call__ (detection.py:727-798) on
  * n_blocks consecutive blocks with the detector state carried in d_state
  * (ofp_stream_state_bytes() bytes, initialised by ofp_stream_state_init).

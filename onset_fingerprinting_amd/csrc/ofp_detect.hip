@@ -1825,7 +1825,8 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64
 }
 
 // phase 0: everything; phase 1: only the asynchronous head (transpose + candidates launch);
-// phase 2: everything after the head (the caller ran phase 1 with the same arguments)
+// phase 2: everything after the head (the caller ran phase 1 with the same arguments);
+// phase 5 + phase 6: phase 1 in two calls, the planar input copy / the IIR candidate launch
 static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
                        float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts,
                        void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_, int phase) {
@@ -1848,10 +1849,12 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     Counters ctr{reinterpret_cast<int*>(ws + l.o_flags), 0, stream};
     int64_t info[OFP_DETECT_INFO_LEN] = {0};
     hipEvent_t* ev = d->ev;
-    if (phase != 2) OFP_HIP(hipEventRecord(ev[0], stream));
+    const bool do_head = phase == 0 || phase == 1 || phase == 5;   // zero fill + transpose
+    const bool do_cand = phase == 0 || phase == 1 || phase == 6;   // the IIR candidate launch
+    if (do_head) OFP_HIP(hipEventRecord(ev[0], stream));
     bool hp_cand_timed = false;
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
-        if (phase == 1) return OFP_OK;
+        if (phase == 1 || phase == 5 || phase == 6) return OFP_OK;
         OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
         OFP_HIP(hipStreamSynchronize(stream));
         if (h_info) std::memcpy(h_info, info, sizeof(info));
@@ -1863,13 +1866,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const size_t tile_lds = (size_t)g.C * (l.tu + 1) * sizeof(float);
 
     // --- transpose in
-    if (phase != 2) {
+    if (do_head) {
         OFP_HIP(hipMemsetAsync(ws + l.o_zero, 0, (size_t)l.zero_bytes, stream));  // counters, flags: see make_layout
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
                            stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
         OFP_LAUNCH_CHECK("k_transpose_in");
         OFP_HIP(hipEventRecord(ev[8], stream));
     }
+    if (phase == 5) return OFP_OK;
 
     // --- hp + dB
     if (p.hp_enabled) {
@@ -1898,14 +1902,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.counters = ctr.base;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         hc.probe = nullptr;
-        const char* probe_path = phase != 2 ? getenv("OFP_HP_PROBE") : nullptr;
+        const char* probe_path = do_cand ? getenv("OFP_HP_PROBE") : nullptr;
         const int64_t probe_waves = cdiv(chains * l.hp_chunks * (l.hp_R / l.hp_span), 64);
         if (probe_path) OFP_HIP(hipMalloc(&hc.probe, probe_waves * 32));
         const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
         const int64_t nC0 = chains * l.hp_chunks;
-        if (phase != 2) {
+        if (do_cand) {
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
             if ((int64_t)cand_grid <= d->n_cus)
                 hipLaunchKernelGGL(k_hp_candidates<true>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
@@ -1937,7 +1941,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             }
             info[12] = steps * chains;
         }
-        if (phase == 1) return OFP_OK;
+        if (phase == 1 || phase == 6) return OFP_OK;
         hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
         OFP_LAUNCH_CHECK("k_hp_plurality");
         for (int it = 0;; ++it) {
@@ -1959,7 +1963,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
         }
     }
-    if (phase == 1) return OFP_OK;  // (no high-pass: the head is the transpose alone)
+    if (phase == 1 || phase == 6) return OFP_OK;  // (no high-pass: the head is the transpose alone)
     OFP_HIP(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, xt, xdb, chains, p.hp_enabled ? 0 : 1,
                        p.floor_db);
@@ -2170,6 +2174,18 @@ int ofp_detect_offline_finish(ofp_detector* d, const float* d_x, int64_t n_clips
                               float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws,
                               int64_t ws_bytes, int64_t* h_info, void* stream) {
     return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info, stream, 2);
+}
+
+int ofp_detect_offline_begin_input(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
+                                   void* d_ws, int64_t ws_bytes, void* stream) {
+    int64_t dummy = 0;
+    return detect_impl(d, d_x, n_clips, N, warm, nullptr, nullptr, 0, &dummy, d_ws, ws_bytes, nullptr, stream, 5);
+}
+
+int ofp_detect_offline_begin_iir(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
+                                 void* d_ws, int64_t ws_bytes, void* stream) {
+    int64_t dummy = 0;
+    return detect_impl(d, d_x, n_clips, N, warm, nullptr, nullptr, 0, &dummy, d_ws, ws_bytes, nullptr, stream, 6);
 }
 
 }  // extern "C"

@@ -139,6 +139,24 @@ class BatchDetector:
         check(self.d.lib.ofp_detect_offline_begin(self.d.handle, x.data_ptr(), n_clips, N, warm, ws.data_ptr(),
                                                   ws.numel(), _stream_ptr(x.device)), "ofp_detect_offline_begin")
 
+    def begin_input(self, x, warm=None):
+        """`begin` in two calls: this one enqueues the planar copy of the input only (after it,
+        `planar_input` is valid on this stream), `begin_iir` the IIR candidate launch."""
+        self._part("ofp_detect_offline_begin_input", x, warm)
+
+    def begin_iir(self, x, warm=None):
+        self._part("ofp_detect_offline_begin_iir", x, warm)
+
+    def _part(self, name, x, warm):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n_clips, N, C = x.shape
+        warm = int(0.5 * self.sr) if warm is None else int(warm)
+        ws = self.reserve(n_clips, N, warm)
+        check(getattr(self.d.lib, name)(self.d.handle, x.data_ptr(), n_clips, N, warm, ws.data_ptr(), ws.numel(),
+                                        _stream_ptr(x.device)), name)
+
     def planar_input(self, x, warm=None):
         """(device address, stride in floats) of the planar copy of `x` (one series per clip and
         channel, `stride` floats apart) that `begin` (or `detect`) left in the work space; valid

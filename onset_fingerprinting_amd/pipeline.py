@@ -83,11 +83,13 @@ class FingerprintPipeline:
             self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             self._head = torch.cuda.Event()
         side = self._side
-        # head of the detector: transpose + the IIR candidate launch (heavy on the memory system)
-        self.detector.begin(x)
+        # head of the detector: transpose + the IIR candidate launch, then its verification rounds
+        # (a handful of waves per launch and a host round trip each: anything else on the chip slows
+        # them several times over)
+        self.detector.begin_input(x)
         self._head.record(main)
-        # the spectral branch starts when the head is done and then shares the chip with the
-        # detector's long, sparsely occupied tail (verification rounds, followers, tracker)
+        self.detector.begin_iir(x)
+        # the spectral branch needs the planar copy only: it starts beside the candidate launch
         side.wait_event(self._head)
         with torch.cuda.stream(side):
             self._ev[0].record(side)
