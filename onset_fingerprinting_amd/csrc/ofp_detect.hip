@@ -1398,6 +1398,8 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
         t_j[lane] = rj;
     };
     int jp = -1;  // previous visited block
+    int64_t r_deb = 0;  // C <= 64: this lane's channel
+    int r_state = 0;
     if (nvis > 0) load_tile(0);
     for (int64_t k0 = 0; k0 < nvis; k0 += TB) {
         __syncthreads();
@@ -1405,6 +1407,59 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
         __syncthreads();
         if (k0 + TB < nvis) load_tile(k0 + TB);
         const int nblk = (int)min<int64_t>(TB, nvis - k0);
+        if (C <= 64) {
+            // up to 64 channels: lane = channel, the channel's state lives in registers
+            // (r_deb, r_state) instead of LDS -- the same steps as the general loop below
+            const bool act = lane < C;
+            for (int bi = 0; bi < nblk; ++bi) {
+                const int j = t_j[bi];
+                const int skipped = j - jp - 1;
+                int f = -1, lbv = -1, pcv = -1;
+                if (act) {
+                    f = t_fc[bi * C + lane];
+                    lbv = t_lb[bi * C + lane];
+                    pcv = t_pc[bi * C + lane];
+                }
+                bool on = false;
+                int oi = 0;
+                if (act) {
+                    if (skipped > 0 && r_deb > 0) r_deb -= (int64_t)B * min<int64_t>(skipped, (r_deb + B - 1) / B);
+                    if (r_state && pcv > jp) r_state = 0;
+                    const bool gate = !r_state && r_deb < 1;  // :764-768 (block-start values)
+                    on = gate && f >= 0;
+                    oi = on ? f : 0;                          // :774
+                }
+                int mx = 0;                                   // :790 on_indices.max() over ALL channels
+                {
+                    unsigned long long fm = __ballot(oi > 0);
+                    while (fm) {
+                        const int l = __builtin_ctzll(fm);
+                        mx = max(mx, __builtin_amdgcn_readlane(oi, l));
+                        fm &= fm - 1;
+                    }
+                }
+                if (act) {
+                    if (on) {                                 // :778-779
+                        r_state = 1;
+                        r_deb = a.cooldown;
+                    }
+                    if (r_deb > 0) r_deb -= B;                // :780
+                    if (lbv >= mx) r_state = 0;               // :784-791
+                }
+                const unsigned long long m = __ballot(on);
+                if (on) {
+                    const int64_t pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < a.cap) {
+                        rec[pos].clip = (int32_t)clip + a.clip_base;
+                        rec[pos].channel = lane;
+                        rec[pos].sample = (int64_t)j * B + oi;  // detection.py:80
+                    }
+                }
+                count += __popcll(m);
+                jp = j;
+            }
+            continue;
+        }
         for (int bi = 0; bi < nblk; ++bi) {
             const int j = t_j[bi];
             const int32_t* fc = t_fc + bi * C;
