@@ -1250,24 +1250,24 @@ __global__ __launch_bounds__(64) void k_last_clear(const int32_t* __restrict__ l
     const int64_t clip = chain / C;
     const int lane = threadIdx.x;
     int carry = -1;
-    constexpr int U = 4;  // 4 x 64 blocks per step: the loads are issued together, the scans follow
+    constexpr int U = 4;  // 4 x 64 blocks per step: the loads are issued together
     for (int64_t j0 = 0; j0 < nb; j0 += 64 * U) {
-        int v[U];
+        int f[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t j = j0 + 64 * u + lane;
-            v[u] = (j < nb && lb[(clip * nb + j) * C + c] >= 0) ? (int)j : -1;
+            f[u] = (j < nb && lb[(clip * nb + j) * C + c] >= 0) ? 1 : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // the last flagged block at or before this lane's: the highest set bit of the ballot
+            // among bits 0..lane (no shuffles: one ballot per 64 blocks)
             const int64_t j = j0 + 64 * u + lane;
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(v[u], o);
-                if (lane >= o) v[u] = max(v[u], t);
-            }
-            v[u] = max(v[u], carry);
-            if (j < nb) pc[(clip * nb + j) * C + c] = v[u];
-            carry = __shfl(v[u], 63);
+            const unsigned long long mask = __ballot(f[u] != 0);
+            const unsigned long long below = mask & ((2ull << lane) - 1ull);
+            const int v = below ? (int)(j0 + 64 * u) + 63 - __builtin_clzll(below) : carry;
+            if (j < nb) pc[(clip * nb + j) * C + c] = v;
+            if (mask) carry = (int)(j0 + 64 * u) + 63 - __builtin_clzll(mask);
         }
     }
 }
