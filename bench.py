@@ -55,7 +55,7 @@ BYTES_MLP = 4 * NMELS + 4 * 8
 # WRITE_SIZE, /opt/skills/guides/MI355X_MICROARCH.md section HBM); filled from profiles/, else null
 TRAFFIC_BYTES_PER_LAUNCH = {}
 try:  # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), see profiles/README.md
-    _t = json.load(open(REPO / "profiles" / "r01" / "v13_pmc_traffic_per_kernel.json"))
+    _t = json.load(open(REPO / "profiles" / "r01" / "v14_pmc_traffic_per_kernel.json"))
     TRAFFIC_BYTES_PER_LAUNCH = {"hp": _t["k_hp_candidates"]["hbm_mb_per_launch"] * 1e6,
                                 "stft_mel": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
 except Exception:
