@@ -6,13 +6,13 @@
 One step = one pass of detect -> rFFT |X|^2 -> 40-mel -> FCNN over one batch of
 synthetic audio already resident in HBM, plus (N > 1) the RCCL all-gather that
 collates onset records.  The detector is a chain of latency-bound recurrences that
-fills a fraction of the chip, so `--inflight` steps (default 6) are in flight at a
+fills a fraction of the chip, so `--inflight` steps (default 8) are in flight at a
 time on each GPU, each on its own pipeline instance (work space, buffers, streams,
 host thread); every step is still one complete pass over one clip, steps complete and
 are gathered in order, and `config.latency_ms_per_step` reports what one step takes
-(`--inflight 1`: strictly one after the other).  In flight, the detector's IIR stage uses its
-throughput setting (`hp_span = 2`, reported as `config.detector_tuning`; results are identical for
-every tuning).  Workload at every N: BASELINE.json configs[1] ("C2":
+(`--inflight 1`: strictly one after the other).  In flight, the detector uses its throughput
+setting (`hp_span = 2`, `mm_chunk = 8192`, reported as `config.detector_tuning`; results are
+identical for every tuning).  Workload at every N: BASELINE.json configs[1] ("C2":
 8 ch x 60 s @ 48 kHz, 1024-point frames, hop 256) per GPU -- each rank owns an
 independent 8-channel clip (channels of one detector are coupled and a stream does
 not shard in time), so scaling is weak.  Rank 0 prints ONE JSON line.
@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=6, help="steps (clips) processed concurrently per GPU")
+    ap.add_argument("--inflight", type=int, default=8, help="steps (clips) processed concurrently per GPU")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
     args = ap.parse_args()
 
@@ -118,10 +118,12 @@ def main():
     D = max(1, args.inflight)
     pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local) for _ in range(D)]
     streams = [torch.cuda.Stream(dev) for _ in range(D)]
-    # With several steps in flight the IIR stage runs in its throughput setting (ofp_detect_tuning.hp_span = 2:
-    # one speculative run serves two chunks -- 2/3 of the work in half the waves, a 0.3 ms longer launch);
-    # the one-step-at-a-time figure below uses a pipeline with the library defaults.
-    tuning = json.loads(args.tuning) if args.tuning else ({"hp_span": 2} if D > 1 else {})
+    # With several steps in flight the detector runs in its throughput setting: ofp_detect_tuning.hp_span = 2
+    # (one speculative IIR run serves two chunks: 2/3 of the work in half the waves, a slightly longer
+    # launch) and mm_chunk = 8192 (tracker chunks twice as long: half the waves and half the overlapping
+    # window reads, 0.1 ms more for a lone step); the one-step-at-a-time figure below uses a pipeline with
+    # the library defaults.
+    tuning = json.loads(args.tuning) if args.tuning else ({"hp_span": 2, "mm_chunk": 8192} if D > 1 else {})
     if tuning:
         for pp in pipes:
             pp.detector.set_tuning(**tuning)

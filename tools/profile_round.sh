@@ -14,8 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -1) $O/kernel_stats.csv
 python tools/trace_concurrency.py $O/stats 20 > $O/concurrency.txt
 # counters per launch do not depend on what else is in flight: one step at a time, with the tuning the default bench uses
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2}' > $O/pmc_f.json 2> $O/pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2}' > $O/pmc_w.json 2> $O/pmc_w.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2, "mm_chunk": 8192}' > $O/pmc_f.json 2> $O/pmc_f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2, "mm_chunk": 8192}' > $O/pmc_w.json 2> $O/pmc_w.err
 cp $(ls $O/pmc_f/*/*counter_collection.csv | tail -1) $O/pmc_fetch_size.csv
 cp $(ls $O/pmc_w/*/*counter_collection.csv | tail -1) $O/pmc_write_size.csv
 python tools/pmc_traffic.py $O/pmc_fetch_size.csv $O/pmc_write_size.csv > $O/pmc_traffic_per_kernel.json
