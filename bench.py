@@ -241,7 +241,7 @@ def main():
                        "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3),
                        "one_step_at_a_time": {"ms_per_step": round(single_ms, 3),
                                               "frames_per_s": round(world * frames_per_rank / (single_ms / 1e3))}},
-            "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm+k_ar_chunk",
+            "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm2+k_ar_chunk",
                                                     "mm": "k_mm_warm2+k_mm_chunk", "db": "k_rect_db",
                                                     "rel": "k_rel_out", "logic": "k_block_scan+k_state_machine",
                                                     "stft_mel": "k_stft_power<1024> (mel fused)", "mlp": "k_dense"}[dom],
