@@ -11,8 +11,11 @@ fetched.  Two thin delegations make ``data.stft`` runnable:
 The reference's ctypes followers look for ``envelope_follower.so`` next to
 ``detection.py`` (detection.py:517-519); /root/reference is read-only, so the
 library is built from the reference's own C file by ``oracle/Makefile`` into
-``oracle/_ref/`` and ``detection.__file__`` is pointed there after import.
+``$OFP_REF_DIR`` (default ``/tmp/ofp_ref``: outside the repository, so nothing built
+from the reference's sources ever travels to the GPU box) and ``detection.__file__``
+is pointed there after import.
 """
+import os
 import sys
 import types
 from pathlib import Path
@@ -22,7 +25,7 @@ import scipy.signal
 
 REPO = Path(__file__).resolve().parents[2]
 REF_ROOT = Path("/root/reference")
-REF_SO_DIR = REPO / "oracle" / "_ref"
+REF_SO_DIR = Path(os.environ.get("OFP_REF_DIR", "/tmp/ofp_ref"))
 
 
 def _pad_center(data, *, size, axis=-1, **kwargs):
