@@ -217,6 +217,15 @@ int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int
                        int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
                        const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
                        float* d_mel, int64_t planar_stride, void* stream);
+/* ... and the classifier on top (the fingerprint path of SURVEY.md 8a rows a9 -> a11 -> a13 in one
+ * launch): the 40 band sums of 16 frames at a time go through the whole FCNN while they are still in
+ * LDS.  d_logits [n_clips][C][H][mlp outputs]; d_power and d_mel may each be NULL (nothing but the
+ * logits then leaves the chip: 32 B per frame instead of 2 052 + 160).  mlp inputs == n_mels. */
+typedef struct ofp_mlp ofp_mlp;
+int ofp_stft_power_mel_mlp(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t n_channels, int32_t n_fft,
+                           int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
+                           const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
+                           float* d_mel, int64_t planar_stride, const ofp_mlp* mlp, float* d_logits, void* stream);
 /* planar_stride != 0: d_x points at one series per (clip, channel), planar_stride floats apart, e.g.
  * the planar copy the detector keeps in its work space between ofp_detect_offline_begin and the next
  * begin (each series there is preceded by the warm-up part of the detector's stream): */
@@ -267,6 +276,22 @@ int ofp_mfcc(const float* d_mel, int64_t n_rows, int32_t n_mels, int32_t n_mfcc,
 int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float* d_w,
               const float* d_b, const float* d_scale, const float* d_shift, int32_t act,
               float* d_y, void* stream);
+/* The whole FCNN (calibration.py:463-527, eval mode) as one handle and ONE launch: n_layers fused
+ * dense layers (1..8) with the activations kept in LDS; per output element the arithmetic is that of
+ * the ofp_dense chain, so results are bit-identical to it.  All arrays are HOST pointers and are copied:
+ * dims [n_layers+1] (dims[0] inputs ... dims[n_layers] outputs), act [n_layers] (OFP_ACT_*), and per
+ * layer h_w[L] [dims[L+1]][dims[L]] (torch Linear.weight), h_b[L] / h_scale[L] / h_shift[L]
+ * [dims[L+1]] or NULL (h_b, h_scale, h_shift themselves may be NULL).  ofp_mlp_forward: d_x [n][dims[0]]
+ * -> d_y [n][dims[n_layers]]; fails with OFP_ERR_INVALID when ofp_mlp_lds_bytes() exceeds the 160 KiB of
+ * LDS (run such a network layer by layer with ofp_dense). */
+typedef struct ofp_mlp ofp_mlp; /* opaque */
+int ofp_mlp_create(int32_t n_layers, const int32_t* dims, const int32_t* act, const float* const* h_w,
+                   const float* const* h_b, const float* const* h_scale, const float* const* h_shift,
+                   ofp_mlp** out);
+int ofp_mlp_destroy(ofp_mlp* mlp);
+int64_t ofp_mlp_lds_bytes(const ofp_mlp* mlp);
+int ofp_mlp_forward(const ofp_mlp* mlp, const float* d_x, int64_t n, float* d_y, void* stream);
+
 /* Conv1d (stride 1, groups 1) + bias + activation: d_x [n][cin][w] ->
  * d_y [n][cout][wout], wout = w + 2*padding - dilation*(k-1)   (model.py:84-95) */
 int ofp_conv1d(const float* d_x, int64_t n, int32_t cin, int32_t w, const float* d_w /*[cout][cin/groups][k]*/,

@@ -101,6 +101,14 @@ SIGNATURES = {
     "ofp_mel": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofp_mfcc": (ctypes.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "ofp_dense": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "ofp_mlp_create": (ctypes.c_int, [_i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_vp),
+                                      ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                      ctypes.POINTER(_vp)]),
+    "ofp_mlp_destroy": (ctypes.c_int, [_vp]),
+    "ofp_mlp_lds_bytes": (_i64, [_vp]),
+    "ofp_mlp_forward": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "ofp_stft_power_mel_mlp": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
+                                              _vp, _i64, _vp, _vp, _vp]),
     "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                                   _i32, _vp, _vp]),

@@ -1,0 +1,189 @@
+// Real FFT building blocks shared by the STFT kernels (csrc/ofp_spectral.hip) and the per-hop
+// streaming kernel (csrc/ofp_hop.hip).
+//
+// An F-point real FFT is an M = F/2 point complex FFT of the packed sequence
+// z[n] = x[2n] + i x[2n+1] followed by one split pass.  The complex FFT is a Stockham autosort
+// FFT with radix-8/4 passes in place in one LDS buffer per frame; the twiddles W_M^k, the split
+// twiddles W_F^k and the window are built in fp64 and rounded once.  T = M/8 lanes cooperate on
+// one frame, so a 1024-point frame is exactly one 64-lane wavefront.
+#pragma once
+#include <cmath>
+
+#include "ofp_common.h"
+
+namespace ofpfft {
+
+using ofp::cdiv;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+__device__ __forceinline__ void dft2(float2& a, float2& b) {
+    float2 t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+__device__ __forceinline__ void dft4(float2* v) {  // outputs in natural order
+    dft2(v[0], v[2]);
+    dft2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    float2 t = v[1];
+    v[1] = v[2];
+    v[2] = t;
+}
+__device__ __forceinline__ void dft8(float2* v) {  // outputs in natural order
+    const float h = 0.70710678118654752440f;
+    dft2(v[0], v[4]);
+    dft2(v[1], v[5]);
+    dft2(v[2], v[6]);
+    dft2(v[3], v[7]);
+    v[5] = make_float2((v[5].x + v[5].y) * h, (v[5].y - v[5].x) * h);   // * W8^1
+    v[6] = mul_mi(v[6]);                                                 // * W8^2
+    v[7] = make_float2((v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h);  // * W8^3
+    dft2(v[0], v[2]);
+    dft2(v[1], v[3]);
+    v[3] = mul_mi(v[3]);
+    dft2(v[4], v[6]);
+    dft2(v[5], v[7]);
+    v[7] = mul_mi(v[7]);
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    dft2(v[4], v[5]);
+    dft2(v[6], v[7]);
+    // bit-reversed -> natural
+    float2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[6]; v[6] = t;
+}
+
+template <int R>
+__device__ __forceinline__ void dftR(float2* v) {
+    if (R == 8) dft8(v);
+    else if (R == 4) dft4(v);
+    else dft2(v[0], v[1]);
+}
+
+// One Stockham pass of radix R over M points held in ONE buffer: every lane first reads the
+// inputs of all its butterflies into registers, a workgroup barrier separates the reads from the
+// writes, so the autosort permutation needs no second buffer (half the LDS per frame, more
+// workgroups per CU).  Ns = product of the radices already done.
+// Barrier between the lanes that share one frame.  Up to 64 lanes per frame, a frame lives inside
+// one wave: its LDS instructions execute in order, so nothing has to wait for the other waves of the
+// workgroup (which work on other frames) -- only the compiler must not move accesses across.
+template <int T>
+__device__ __forceinline__ void frame_sync() {
+    if constexpr (T <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int R, int M, int T>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
+    constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
+    static_assert((M / R) % T == 0 && NB >= 1, "lanes per frame must divide the butterflies of a pass");
+    float2 v[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[b][i] = buf[j + i * (M / R)];
+    }
+    frame_sync<T>();  // all reads of this pass are done
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+        const int k = j & (Ns - 1);
+        const int tstep = k * (M / (Ns * R));
+        if (Ns > 1) {  // the first pass has k = 0: every twiddle is 1
+#pragma unroll
+            for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
+        }
+        dftR<R>(v[b]);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int i = 0; i < R; ++i) buf[j0 + i * Ns] = v[b][i];
+    }
+    frame_sync<T>();  // all writes are visible to the next pass
+}
+
+template <int M> struct Radices;
+template <> struct Radices<128>  { static constexpr int n = 3; static constexpr int r[4] = {8, 4, 4, 1}; };
+template <> struct Radices<256>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 4, 1}; };
+template <> struct Radices<512>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
+template <> struct Radices<1024> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
+template <> struct Radices<2048> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
+
+// complex FFT, in place, of the M points in `a` (every thread of the workgroup calls this
+// together: the passes contain workgroup barriers).
+template <int M, int T>
+__device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
+    using Rx = Radices<M>;
+    int Ns = 1;
+    frame_sync<T>();  // the frame has been written
+#pragma unroll
+    for (int p = 0; p < Rx::n; ++p) {
+        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
+        else fft_pass<4, M, T>(a, tw, Ns, tid);
+        Ns *= Rx::r[p];
+    }
+}
+
+template <int F>
+struct Cfg {
+    static constexpr int M = F / 2;
+    static constexpr int T = (M / 8) < 16 ? 16 : (M / 8);   // lanes per frame
+    static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
+    static constexpr int FPW = WG / T;                      // frames per workgroup iteration
+    // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
+    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * M * 8;
+};
+
+template <int F>
+__device__ __forceinline__ void build_tables(float2* twM, float2* twF, float* win, int frame_length) {
+    constexpr int M = F / 2;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)M, &s, &c);
+        twM[k] = make_float2((float)c, (float)s);
+    }
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)F, &s, &c);
+        twF[k] = make_float2((float)c, (float)s);
+    }
+    if (win) {
+        // periodic Hann of `frame_length`, centre-padded to F (data.py:627-629)
+        const int lpad = (F - frame_length) / 2;
+        for (int n = threadIdx.x; n < F; n += blockDim.x) {
+            int q = n - lpad;
+            double w = 0.0;
+            if (q >= 0 && q < frame_length) w = 0.5 - 0.5 * cospi(2.0 * (double)q / (double)frame_length);
+            win[n] = (float)w;
+        }
+    }
+}
+
+// X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
+template <int M>
+__device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, int k) {
+    float2 zk = Z[k & (M - 1)];
+    float2 zm = Z[(M - k) & (M - 1)];
+    zm.y = -zm.y;
+    float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+    float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
+    float2 t = cmul(twF[k], o);
+    return cadd(e, mul_mi(t));
+}
+
+}  // namespace ofpfft

@@ -2,23 +2,20 @@
 // cores (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain) and a direct
 // Conv1d + activation.  Reference: calibration.py:463-527 (FCNN, eval mode,
 // BatchNorm1d folded into scale/shift by the host), model.py:52-120 (CNN).
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
 #include "ofp_common.h"
+#include "ofp_mlp.h"
 
 namespace {
 
 using ofp::cdiv;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef ofp_f32x4 f32x4;
 
-__device__ __forceinline__ float activate(float v, int act) {
-    switch (act) {
-        case OFP_ACT_RELU: return v > 0.0f ? v : 0.0f;
-        case OFP_ACT_SILU: return v / (1.0f + expf(-v));
-        case OFP_ACT_LEAKYRELU: return v >= 0.0f ? v : 0.01f * v;
-        case OFP_ACT_ELU: return v > 0.0f ? v : expm1f(v);
-        case OFP_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
+__device__ __forceinline__ float activate(float v, int act) { return ofp_activate(v, act); }
 
 // One wave computes a 16-row x 16-column output tile per MFMA chain.
 // A fragment: lane l holds x[row0 + (l&15)][k0 + (l>>4)]
@@ -61,6 +58,36 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ x, int6
                 }
             }
         }
+    }
+}
+
+// The whole network in one launch (ofp_mlp.h): the parameters are copied to LDS once per workgroup,
+// every wave takes 16-row tiles (grid stride), loads the rows with coalesced reads into its tile A and
+// runs all layers there.  LDS: params, then per wave tile A [16][st_a] and tile B [16][st_b].
+constexpr int MLP_WAVES = 4;
+__global__ __launch_bounds__(64 * MLP_WAVES) void k_mlp(MlpPlan p, const float* __restrict__ x, int64_t n,
+                                                        float* __restrict__ y) {
+    extern __shared__ __align__(16) float sm[];
+    float* prm = sm;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* ta = sm + ((p.n_params + 3) & ~3) + (size_t)w * 16 * (p.st_a + p.st_b);
+    float* tb = ta + 16 * p.st_a;
+    for (int i = threadIdx.x; i < p.n_params; i += blockDim.x) prm[i] = p.params[i];
+    __syncthreads();
+    const int in = p.dims[0], out = p.dims[p.n_layers];
+    const int64_t row_tiles = cdiv(n, 16);
+    for (int64_t rt = (int64_t)blockIdx.x * MLP_WAVES + w; rt < row_tiles; rt += (int64_t)gridDim.x * MLP_WAVES) {
+        const int64_t r0 = rt * 16;
+        const int nr = (int)min<int64_t>(16, n - r0);
+        const float* src = x + r0 * in;
+        for (int i = lane; i < 16 * in; i += 64) {
+            const int r = i / in, k = i - r * in;
+            ta[r * p.st_a + k] = r < nr ? src[i] : 0.0f;
+        }
+        ofp_wave_lds_sync();
+        ofp_mlp_tile(p, prm, ta, tb, lane, [&](int row, int col, float v) {
+            if (row < nr) y[(r0 + row) * out + col] = v;
+        });
     }
 }
 
@@ -228,6 +255,90 @@ int ofp_dense(const float* d_x, int64_t n, int32_t in, int32_t out, const float*
     hipLaunchKernelGGL(k_dense, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, n, in, out, d_w, d_b,
                        d_scale, d_shift, act, d_y);
     OFP_LAUNCH_CHECK("k_dense");
+    return OFP_OK;
+}
+
+// ---- whole-network handle -----------------------------------------------------------------
+int ofp_mlp_create(int32_t n_layers, const int32_t* dims, const int32_t* act, const float* const* h_w,
+                   const float* const* h_b, const float* const* h_scale, const float* const* h_shift,
+                   ofp_mlp** out) {
+    OFP_REQUIRE(dims && act && h_w && out, "ofp_mlp_create: NULL argument");
+    OFP_REQUIRE(n_layers >= 1 && n_layers <= OFP_MLP_MAX_LAYERS, "ofp_mlp_create: %d layers (1..%d supported)", n_layers,
+                OFP_MLP_MAX_LAYERS);
+    MlpPlan p;
+    std::memset(&p, 0, sizeof(p));
+    p.n_layers = n_layers;
+    std::vector<float> host;
+    int wa = 1, wb = 1;
+    for (int L = 0; L <= n_layers; ++L) {
+        OFP_REQUIRE(dims[L] >= 1 && dims[L] <= 4096, "ofp_mlp_create: layer width %d out of range", dims[L]);
+        p.dims[L] = dims[L];
+        if (L < n_layers) (L % 2 == 0 ? wa : wb) = std::max(L % 2 == 0 ? wa : wb, dims[L]);
+    }
+    auto put = [&](const float* src, int count) {
+        const int off = (int)host.size();
+        host.insert(host.end(), src, src + count);
+        while (host.size() % 4) host.push_back(0.0f);
+        return off;
+    };
+    for (int L = 0; L < n_layers; ++L) {
+        OFP_REQUIRE(h_w[L], "ofp_mlp_create: layer %d has no weight", L);
+        OFP_REQUIRE(act[L] >= OFP_ACT_IDENTITY && act[L] <= OFP_ACT_TANH, "ofp_mlp_create: unknown activation %d", act[L]);
+        OFP_REQUIRE((!h_scale || !h_scale[L]) == (!h_shift || !h_shift[L]), "ofp_mlp_create: give both scale and shift");
+        p.act[L] = act[L];
+        p.w_off[L] = put(h_w[L], dims[L] * dims[L + 1]);
+        p.b_off[L] = (h_b && h_b[L]) ? put(h_b[L], dims[L + 1]) : -1;
+        p.sc_off[L] = (h_scale && h_scale[L]) ? put(h_scale[L], dims[L + 1]) : -1;
+        p.sh_off[L] = (h_shift && h_shift[L]) ? put(h_shift[L], dims[L + 1]) : -1;
+    }
+    p.n_params = (int)host.size();
+    p.st_a = wa | 1;  // odd strides: the 16 rows of a fragment read fall into different LDS banks
+    p.st_b = wb | 1;
+    ofp_mlp* m = new (std::nothrow) ofp_mlp();
+    if (!m) return ofp::fail(OFP_ERR_INVALID, "out of host memory");
+    hipError_t e = hipMalloc(&m->d_params, host.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->d_params) (void)hipFree(m->d_params);
+        delete m;
+        return ofp::fail(OFP_ERR_HIP, "ofp_mlp_create: %s", hipGetErrorString(e));
+    }
+    p.params = m->d_params;
+    m->plan = p;
+    *out = m;
+    return OFP_OK;
+}
+
+int ofp_mlp_destroy(ofp_mlp* m) {
+    if (!m) return OFP_OK;
+    if (m->d_params) (void)hipFree(m->d_params);
+    delete m;
+    return OFP_OK;
+}
+
+int64_t ofp_mlp_lds_bytes(const ofp_mlp* m) {
+    if (!m) return -1;
+    const MlpPlan& p = m->plan;
+    return ((int64_t)((p.n_params + 3) & ~3) + (int64_t)MLP_WAVES * 16 * (p.st_a + p.st_b)) * 4;
+}
+
+int ofp_mlp_forward(const ofp_mlp* m, const float* d_x, int64_t n, float* d_y, void* stream) {
+    OFP_REQUIRE(m, "ofp_mlp_forward: NULL handle");
+    if (n == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_y && n > 0, "ofp_mlp_forward: NULL argument");
+    const size_t lds = (size_t)ofp_mlp_lds_bytes(m);
+    OFP_REQUIRE(lds <= 160 * 1024, "ofp_mlp_forward: the network (%d parameters) does not fit the LDS; run it layer by "
+                "layer with ofp_dense", m->plan.n_params);
+    static size_t attr_set = 0;
+    if (lds > 65536 && lds > attr_set) {
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_set = lds;
+    }
+    const int64_t row_tiles = cdiv(n, 16);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv(row_tiles, MLP_WAVES), 256 * 8);
+    hipLaunchKernelGGL(k_mlp, dim3(grid), dim3(64 * MLP_WAVES), lds, (hipStream_t)stream, m->plan, d_x, n, d_y);
+    OFP_LAUNCH_CHECK("k_mlp");
     return OFP_OK;
 }
 

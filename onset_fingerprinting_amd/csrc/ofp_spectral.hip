@@ -14,181 +14,14 @@
 #include <cmath>
 
 #include "ofp_common.h"
+#include "ofp_fft.h"
+#include "ofp_mlp.h"
 
 namespace {
 
 using ofp::cdiv;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by -i
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
-
-__device__ __forceinline__ void dft2(float2& a, float2& b) {
-    float2 t = csub(a, b);
-    a = cadd(a, b);
-    b = t;
-}
-__device__ __forceinline__ void dft4(float2* v) {  // outputs in natural order
-    dft2(v[0], v[2]);
-    dft2(v[1], v[3]);
-    v[3] = mul_mi(v[3]);
-    dft2(v[0], v[1]);
-    dft2(v[2], v[3]);
-    float2 t = v[1];
-    v[1] = v[2];
-    v[2] = t;
-}
-__device__ __forceinline__ void dft8(float2* v) {  // outputs in natural order
-    const float h = 0.70710678118654752440f;
-    dft2(v[0], v[4]);
-    dft2(v[1], v[5]);
-    dft2(v[2], v[6]);
-    dft2(v[3], v[7]);
-    v[5] = make_float2((v[5].x + v[5].y) * h, (v[5].y - v[5].x) * h);   // * W8^1
-    v[6] = mul_mi(v[6]);                                                 // * W8^2
-    v[7] = make_float2((v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h);  // * W8^3
-    dft2(v[0], v[2]);
-    dft2(v[1], v[3]);
-    v[3] = mul_mi(v[3]);
-    dft2(v[4], v[6]);
-    dft2(v[5], v[7]);
-    v[7] = mul_mi(v[7]);
-    dft2(v[0], v[1]);
-    dft2(v[2], v[3]);
-    dft2(v[4], v[5]);
-    dft2(v[6], v[7]);
-    // bit-reversed -> natural
-    float2 t;
-    t = v[1]; v[1] = v[4]; v[4] = t;
-    t = v[3]; v[3] = v[6]; v[6] = t;
-}
-
-template <int R>
-__device__ __forceinline__ void dftR(float2* v) {
-    if (R == 8) dft8(v);
-    else if (R == 4) dft4(v);
-    else dft2(v[0], v[1]);
-}
-
-// One Stockham pass of radix R over M points held in ONE buffer: every lane first reads the
-// inputs of all its butterflies into registers, a workgroup barrier separates the reads from the
-// writes, so the autosort permutation needs no second buffer (half the LDS per frame, more
-// workgroups per CU).  Ns = product of the radices already done.
-// Barrier between the lanes that share one frame.  Up to 64 lanes per frame, a frame lives inside
-// one wave: its LDS instructions execute in order, so nothing has to wait for the other waves of the
-// workgroup (which work on other frames) -- only the compiler must not move accesses across.
-template <int T>
-__device__ __forceinline__ void frame_sync() {
-    if constexpr (T <= 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
-}
-
-template <int R, int M, int T>
-__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
-    constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
-    static_assert((M / R) % T == 0 && NB >= 1, "lanes per frame must divide the butterflies of a pass");
-    float2 v[NB][R];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = tid + b * T;
-#pragma unroll
-        for (int i = 0; i < R; ++i) v[b][i] = buf[j + i * (M / R)];
-    }
-    frame_sync<T>();  // all reads of this pass are done
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = tid + b * T;
-        const int k = j & (Ns - 1);
-        const int tstep = k * (M / (Ns * R));
-        if (Ns > 1) {  // the first pass has k = 0: every twiddle is 1
-#pragma unroll
-            for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
-        }
-        dftR<R>(v[b]);
-        const int j0 = (j - k) * R + k;
-#pragma unroll
-        for (int i = 0; i < R; ++i) buf[j0 + i * Ns] = v[b][i];
-    }
-    frame_sync<T>();  // all writes are visible to the next pass
-}
-
-template <int M> struct Radices;
-template <> struct Radices<128>  { static constexpr int n = 3; static constexpr int r[4] = {8, 4, 4, 1}; };
-template <> struct Radices<256>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 4, 1}; };
-template <> struct Radices<512>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
-template <> struct Radices<1024> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 4, 4}; };
-template <> struct Radices<2048> { static constexpr int n = 4; static constexpr int r[4] = {8, 8, 8, 4}; };
-
-// complex FFT, in place, of the M points in `a` (every thread of the workgroup calls this
-// together: the passes contain workgroup barriers).
-template <int M, int T>
-__device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
-    using Rx = Radices<M>;
-    int Ns = 1;
-    frame_sync<T>();  // the frame has been written
-#pragma unroll
-    for (int p = 0; p < Rx::n; ++p) {
-        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
-        else fft_pass<4, M, T>(a, tw, Ns, tid);
-        Ns *= Rx::r[p];
-    }
-}
-
-template <int F>
-struct Cfg {
-    static constexpr int M = F / 2;
-    static constexpr int T = (M / 8) < 16 ? 16 : (M / 8);   // lanes per frame
-    static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
-    static constexpr int FPW = WG / T;                      // frames per workgroup iteration
-    // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
-    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * M * 8;
-};
-
-template <int F>
-__device__ __forceinline__ void build_tables(float2* twM, float2* twF, float* win, int frame_length) {
-    constexpr int M = F / 2;
-    for (int k = threadIdx.x; k < M; k += blockDim.x) {
-        double s, c;
-        sincospi(-2.0 * (double)k / (double)M, &s, &c);
-        twM[k] = make_float2((float)c, (float)s);
-    }
-    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
-        double s, c;
-        sincospi(-2.0 * (double)k / (double)F, &s, &c);
-        twF[k] = make_float2((float)c, (float)s);
-    }
-    if (win) {
-        // periodic Hann of `frame_length`, centre-padded to F (data.py:627-629)
-        const int lpad = (F - frame_length) / 2;
-        for (int n = threadIdx.x; n < F; n += blockDim.x) {
-            int q = n - lpad;
-            double w = 0.0;
-            if (q >= 0 && q < frame_length) w = 0.5 - 0.5 * cospi(2.0 * (double)q / (double)frame_length);
-            win[n] = (float)w;
-        }
-    }
-}
-
-// X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
-template <int M>
-__device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, int k) {
-    float2 zk = Z[k & (M - 1)];
-    float2 zm = Z[(M - k) & (M - 1)];
-    zm.y = -zm.y;
-    float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
-    float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
-    float2 t = cmul(twF[k], o);
-    return cadd(e, mul_mi(t));
-}
+using namespace ofpfft;
 
 // ---- dense power spectra --------------------------------------------------
 // Mel filterbank applied in the epilogue of k_stft_power (band-CSR as for ofp_mel): the power
@@ -199,13 +32,35 @@ struct MelFuse {
     const float* w;
     int n_mels, nnz;
     float* mel;  // [total_frames][n_mels]; NULL: no mel output
+    int on;      // take the band sums (mel output and / or the classifier epilogue)
+};
+
+// Classifier epilogue (MLP = true): the band sums of 16 frames are collected in an LDS tile per
+// tile group (the lanes that share one tile: a wave, or the 128 / 256 lanes of a 2048 / 4096-point
+// frame) and pushed through the whole FCNN there (ofp_mlp.h), so neither the power spectrum nor
+// the mel bands have to round-trip HBM for the logits.  Tile B of the network aliases the group's
+// FFT buffers, which are idle between two frames.
+struct MlpFuse {
+    MlpPlan plan;
+    float* logits;  // [total_frames][plan.dims[n_layers]]
 };
 
 template <int F>
+struct TileCfg {
+    static constexpr int T = Cfg<F>::T;
+    static constexpr int TG = T < 64 ? 64 : T;   // lanes per tile group
+    static constexpr int FG = TG / T;            // frames a group finishes per iteration
+    static constexpr int NGRP = Cfg<F>::WG / TG; // tile groups per workgroup
+    static constexpr int ITERS = 16 / FG;        // iterations that fill a 16-row tile
+};
+
+template <int F, bool MLP>
 __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
-                                                            float* __restrict__ power, MelFuse mf, int64_t planar) {
+                                                            float* __restrict__ power, MelFuse mf, int64_t planar,
+                                                            MlpFuse ml) {
     using G = Cfg<F>;
+    using TC = TileCfg<F>;
     constexpr int M = G::M, T = G::T, FPW = G::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
     float2* twM = reinterpret_cast<float2*>(smem);
@@ -218,7 +73,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     int32_t* flo = reinterpret_cast<int32_t*>(fw + mf.nnz);
     int32_t* flen = flo + mf.n_mels;
     int32_t* foff = flen + mf.n_mels;
-    if (mf.mel) {
+    if (mf.on) {
         for (int i = threadIdx.x; i < mf.nnz; i += blockDim.x) fw[i] = mf.w[i];
         for (int i = threadIdx.x; i < mf.n_mels; i += blockDim.x) {
             flo[i] = mf.lo[i];
@@ -230,6 +85,22 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
     float2* A = bufs + (size_t)sub * M;
+    // classifier epilogue: parameters, one tile A and 16 frame indices per tile group
+    float* mprm = reinterpret_cast<float*>(foff + mf.n_mels);
+    float* tileA = nullptr;
+    float* tileB = nullptr;
+    long long* rowf = nullptr;
+    int it_tile = 0;
+    if (MLP) {
+        const int grp_id = threadIdx.x / TC::TG;
+        float* tiles = mprm + ((ml.plan.n_params + 3) & ~3);
+        tileA = tiles + (size_t)grp_id * 16 * ml.plan.st_a;
+        rowf = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(tiles + (size_t)TC::NGRP * 16 * ml.plan.st_a) + 7) &
+                                            ~(uintptr_t)7) + grp_id * 16;
+        tileB = reinterpret_cast<float*>(bufs + (size_t)grp_id * TC::FG * M);
+        for (int i = threadIdx.x; i < ml.plan.n_params; i += blockDim.x) mprm[i] = ml.plan.params[i];
+        if ((threadIdx.x % TC::TG) < 16) rowf[threadIdx.x % TC::TG] = -1;
+    }
     const int64_t n_groups = cdiv(total_frames, FPW);
     // the samples of a frame are fetched one iteration ahead into registers, so that the global
     // loads of frame g+1 are in flight while frame g goes through the FFT
@@ -286,13 +157,14 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             for (int q = 0; q < NK; ++q)
                 if (tid + q * T <= M) dst[tid + q * T] = pk[q];
         }
-        if (mf.mel) {
+        if (mf.on) {
             frame_sync<T>();  // every bin of the spectrum has been read
             float* pf = reinterpret_cast<float*>(A);
 #pragma unroll
             for (int q = 0; q < NK; ++q)
                 if (tid + q * T <= M) pf[tid + q * T] = pk[q];
             frame_sync<T>();
+            const int row = MLP ? it_tile * TC::FG + (sub % TC::FG) : 0;
             if (valid) {
                 for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
                     const float* p = pf + flo[b];
@@ -301,8 +173,29 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
                     const int nb_ = flen[b];
 #pragma unroll 4
                     for (int k = 0; k < nb_; ++k) acc = fmaf(p[k], wb[k], acc);
-                    mf.mel[f * mf.n_mels + b] = acc;
+                    if (mf.mel) mf.mel[f * mf.n_mels + b] = acc;
+                    if (MLP) tileA[row * ml.plan.st_a + b] = acc;
                 }
+            }
+            if (MLP && tid == 0) rowf[row] = valid ? (long long)f : -1;
+        }
+        if (MLP) {
+            // a tile is pushed through the network when its 16 rows are filled, or at the last iteration
+            it_tile += 1;
+            if (it_tile == TC::ITERS || grp + gridDim.x >= n_groups) {
+                frame_sync<TC::TG>();  // tile A complete; the group's FFT buffers are idle
+                if ((threadIdx.x % TC::TG) < 64) {
+                    const int lane = threadIdx.x & 63;
+                    const int nout = ml.plan.dims[ml.plan.n_layers];
+                    ofp_mlp_tile(ml.plan, mprm, tileA, tileB, lane, [&](int r, int col, float v) {
+                        const long long fr = rowf[r];
+                        if (fr >= 0) ml.logits[fr * nout + col] = v;
+                    });
+                    ofp_wave_lds_sync();
+                    if (lane < 16) rowf[lane] = -1;
+                }
+                frame_sync<TC::TG>();  // tile B (the FFT buffers) is free again
+                it_tile = 0;
             }
         }
     }
@@ -434,24 +327,41 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
     }
 }
 
-template <int F>
-int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
-                 const MelFuse& mf, int64_t planar, hipStream_t stream) {
+template <int F, bool MLP>
+int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
+                   const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
     using G = Cfg<F>;
+    using TC = TileCfg<F>;
     size_t lds = G::lds_bytes;
-    if (mf.mel) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
+    if (mf.on) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
+    if (MLP) {
+        // tile B lives in the tile group's idle FFT buffers
+        OFP_REQUIRE((size_t)16 * ml.plan.st_b * 4 <= (size_t)TC::FG * G::M * 8,
+                    "classifier epilogue: hidden layers wider than %d do not fit the FFT buffers of a %d-point frame",
+                    (int)((size_t)TC::FG * G::M * 8 / 64) - 1, F);
+        lds += (size_t)((ml.plan.n_params + 3) & ~3) * 4 + (size_t)TC::NGRP * 16 * ml.plan.st_a * 4 +
+               (size_t)TC::NGRP * 16 * 8 + 16;
+        OFP_REQUIRE(lds <= 160 * 1024, "classifier epilogue: %zu bytes of LDS needed, 160 KiB available", lds);
+    }
     static size_t attr_set = 0;
     if (lds > 65536 && lds > attr_set) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F>),
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F, MLP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
-    hipLaunchKernelGGL(k_stft_power<F>, dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
-                       power, mf, planar);
+    hipLaunchKernelGGL((k_stft_power<F, MLP>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
+                       power, mf, planar, ml);
     OFP_LAUNCH_CHECK("k_stft_power");
     return OFP_OK;
+}
+
+template <int F>
+int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
+                 const MelFuse& mf, int64_t planar, const MlpFuse* ml, hipStream_t stream) {
+    if (ml) return launch_power_t<F, true>(x, n_samples, C, hop, H, total, power, mf, planar, *ml, stream);
+    return launch_power_t<F, false>(x, n_samples, C, hop, H, total, power, mf, planar, MlpFuse{}, stream);
 }
 
 template <int F>
@@ -475,19 +385,20 @@ int launch_frames(const FrameArgs& a, hipStream_t stream) {
 extern "C" {
 
 static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
-                           int32_t hop, float* d_power, const MelFuse& mf, int64_t planar, void* stream_) {
-    OFP_REQUIRE(d_x && (d_power || mf.mel), "ofp_stft_power: NULL argument");
+                           int32_t hop, float* d_power, const MelFuse& mf, int64_t planar, void* stream_,
+                           const MlpFuse* ml = nullptr) {
+    OFP_REQUIRE(d_x && (d_power || mf.mel || ml), "ofp_stft_power: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && C >= 1 && hop >= 1, "ofp_stft_power: bad sizes");
     if (n_samples < n_fft) return OFP_OK;  // no complete frame
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t H = 1 + (n_samples - n_fft) / hop;
     const int64_t total = n_clips * C * H;
     switch (n_fft) {
-        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
-        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
-        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
-        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
-        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, stream);
+        case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
+        case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
+        case 1024: return launch_power<1024>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
+        case 2048: return launch_power<2048>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
+        case 4096: return launch_power<4096>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
         default: return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", n_fft);
     }
 }
@@ -505,8 +416,24 @@ int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int
                 "ofp_stft_power_mel: NULL / empty filterbank");
     OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel: filterbank with %d weights for %d bins", fb_nnz,
                 n_fft / 2 + 1);
-    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel};
+    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1};
     return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream);
+}
+
+int ofp_stft_power_mel_mlp(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, int32_t n_fft,
+                           int32_t hop, float* d_power, int32_t n_mels, const int32_t* d_fb_lo,
+                           const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, int32_t fb_nnz,
+                           float* d_mel, int64_t planar_stride, const ofp_mlp* mlp, float* d_logits, void* stream) {
+    OFP_REQUIRE(d_fb_lo && d_fb_len && d_fb_off && d_fb_w && n_mels >= 1 && fb_nnz >= 1,
+                "ofp_stft_power_mel_mlp: NULL / empty filterbank");
+    OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel_mlp: filterbank with %d weights for %d bins", fb_nnz,
+                n_fft / 2 + 1);
+    OFP_REQUIRE(mlp && d_logits, "ofp_stft_power_mel_mlp: NULL classifier / output");
+    OFP_REQUIRE(mlp->plan.dims[0] == n_mels, "ofp_stft_power_mel_mlp: the classifier takes %d inputs, the filterbank has %d bands",
+                mlp->plan.dims[0], n_mels);
+    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1};
+    MlpFuse ml{mlp->plan, d_logits};
+    return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream, &ml);
 }
 
 int ofp_stft_frames(const float* d_x, int64_t n_clips, int64_t n_samples, int32_t C, const int32_t* d_clip,

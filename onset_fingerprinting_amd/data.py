@@ -119,6 +119,34 @@ def stft_power_mel_dense(x, n_fft, hop, melbank, out_power=None, out_mel=None, w
     return (out_power if want_power else None), out_mel
 
 
+def stft_power_mel_mlp_dense(x, n_fft, hop, melbank, mlp, out_power=None, out_mel=None, out_logits=None,
+                             want_power=False, want_mel=True, planar=None):
+    """`stft_power_mel_dense` with the classifier in the same kernel (``ofp_stft_power_mel_mlp``): the
+    band sums of 16 frames at a time go through the whole FCNN while still in LDS.  `mlp` is a
+    `calibration.DeviceMLP` (``FCNN.device_mlp()``).  Returns (power or None, mel or None,
+    logits [n_clips, C, H, n_out])."""
+    if n_fft not in SUPPORTED_NFFT:
+        raise ValueError(f"n_fft must be one of {SUPPORTED_NFFT}, got {n_fft}")
+    L = _lib.lib()
+    n_clips, N, C = x.shape
+    H = 0 if N < n_fft else 1 + (N - n_fft) // hop
+    if want_power and out_power is None:
+        out_power = torch.empty((n_clips, C, H, n_fft // 2 + 1), dtype=torch.float32, device=x.device)
+    if want_mel and out_mel is None:
+        out_mel = torch.empty((n_clips, C, H, melbank.n_mels), dtype=torch.float32, device=x.device)
+    if out_logits is None:
+        out_logits = torch.empty((n_clips, C, H, mlp.n_out), dtype=torch.float32, device=x.device)
+    if H:
+        check(L.ofp_stft_power_mel_mlp(planar[0] if planar else x.data_ptr(), n_clips, N, C, n_fft, hop,
+                                       out_power.data_ptr() if want_power else None, melbank.n_mels,
+                                       melbank.lo.data_ptr(), melbank.len.data_ptr(), melbank.off.data_ptr(),
+                                       melbank.w.data_ptr(), melbank.w.numel(),
+                                       out_mel.data_ptr() if want_mel else None, planar[1] if planar else 0,
+                                       mlp.handle, out_logits.data_ptr(), _stream(x.device)),
+              "ofp_stft_power_mel_mlp")
+    return (out_power if want_power else None), (out_mel if want_mel else None), out_logits
+
+
 def batch_cc(a: torch.Tensor, b: torch.Tensor):
     """data.py:226-230: full cross-correlation of row i of `a` with row i of `b`,
     [n, length] x [n, length] -> [n, 2*length - 1] (what the grouped F.conv1d there computes)."""

@@ -55,6 +55,62 @@ def test_fcnn_large_batch_and_ragged_rows():
         assert rel_err(y, oracle.fcnn_forward(sd, x.numpy())) < 1e-4
 
 
+def _bits(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(input_size=40, output_size=8),
+    dict(input_size=2, output_size=2, hidden_layers=[16, 12], activation=torch.nn.SiLU, batch_norm=False),
+    dict(input_size=14, output_size=3, hidden_layers=[32], activation=torch.nn.ELU, bias=False),
+    dict(input_size=37, output_size=19, hidden_layers=[40, 33, 17, 5], activation=torch.nn.LeakyReLU),
+    dict(input_size=5, output_size=70, hidden_layers=[], activation=torch.nn.Tanh),
+])
+def test_fused_fcnn_is_bit_identical_to_the_layer_chain(kw):
+    """ofp_mlp_forward (one launch, activations in LDS) against the ofp_dense chain of round 1: the
+    same MFMA chain per output element, hence the same bits -- also for ragged row counts, widths
+    that are no multiple of 4 or 16, several column tiles and networks without hidden layers."""
+    from onset_fingerprinting_amd.calibration import FCNN
+    torch.manual_seed(3)
+    m = FCNN(**kw).eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+    assert m.device_mlp(0).fits
+    for n in (1, 16, 33, 4099):
+        x = torch.randn(n, kw["input_size"]).cuda()
+        assert np.array_equal(_bits(m(x)), _bits(m.forward_layerwise(x))), (kw, n)
+
+
+def test_fcnn_plan_follows_parameter_updates_and_refuses_training_mode():
+    """the folded device copy must not go stale after in-place updates, a submodule
+    load_state_dict or init_eye_weights; training-mode BatchNorm / Dropout is refused."""
+    from onset_fingerprinting_amd.calibration import FCNN
+    torch.manual_seed(5)
+    m = FCNN(6, 3, hidden_layers=[7]).eval()
+    x = torch.randn(9, 6)
+    y0 = m(x).numpy()
+    with torch.no_grad():
+        m.network[0].weight.mul_(2.0)                      # in place
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    y1 = m(x).numpy()
+    assert not np.allclose(y0, y1) and rel_err(y1, oracle.fcnn_forward(sd, x.numpy())) < 1e-4
+    m.network[0].load_state_dict({"weight": torch.randn(7, 6), "bias": torch.zeros(7)})   # submodule
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    assert rel_err(m(x).numpy(), oracle.fcnn_forward(sd, x.numpy())) < 1e-4
+    m.init_eye_weights(m.network[0])                       # replaces .data
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    assert rel_err(m(x).numpy(), oracle.fcnn_forward(sd, x.numpy())) < 1e-4
+    m.network[1].running_mean.add_(0.25)                   # buffer in place
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    assert rel_err(m(x).numpy(), oracle.fcnn_forward(sd, x.numpy())) < 1e-4
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(x)
+    FCNN(6, 3, hidden_layers=[7], batch_norm=False).train()(x)  # nothing mode-dependent: allowed
+
+
 def test_cnn_matches_reference_golden():
     from onset_fingerprinting_amd.model import CNN
     g = load_golden("g8_models")

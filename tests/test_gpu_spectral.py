@@ -80,6 +80,62 @@ def test_dense_power_matches_oracle(data, n_fft, hop, C):
             assert err < RTOL, (clip, c, err)
 
 
+def elementwise_rel(got, ref, floor_frac=1e-6):
+    """max |got - ref| / |ref| over the elements with |ref| >= floor_frac * max|ref| (the floor below
+    which an fp32 FFT's absolute error, ~1e-7 of the largest bin, exceeds the bin itself)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    big = np.abs(ref) >= floor_frac * np.abs(ref).max()
+    return float((np.abs(got - ref)[big] / np.abs(ref)[big]).max()), float(big.mean())
+
+
+@pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 3), (256, 64, 2), (512, 128, 1), (4096, 1024, 2)])
+def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
+    """north_star: "1e-4 relative fp32" -- ELEMENT-wise, not only norm-wise: every power bin that is at
+    least 1e-6 of the largest bin of its channel (an fp32 FFT's error floor is ~1e-7 of the largest
+    bin, so smaller bins carry no relative accuracy in the reference's complex64 either) and EVERY mel
+    band (sums of non-negative terms, no cancellation) within 1e-4 of the fp64 oracle."""
+    from onset_fingerprinting_amd.data import MelBank, stft_power_mel_dense
+    rng = np.random.default_rng(n_fft + 1)
+    N = n_fft * 9 + 11
+    # broadband noise + a strong tone + a hit: bins spread over ~8 decades
+    t = np.arange(N)[:, None]
+    x = (rng.standard_normal((N, C)) * 1e-3 + 0.5 * np.sin(2 * np.pi * 0.0731 * t) +
+         (t > N // 2) * np.exp(-(t - N // 2) / 300.0) * rng.standard_normal((N, C))).astype(np.float32)
+    mb = MelBank(48000, n_fft, 40)
+    P, mel = stft_power_mel_dense(torch.from_numpy(x).cuda()[None], n_fft, hop, mb)
+    P, mel = P[0].cpu().numpy(), mel[0].cpu().numpy()
+    ref = oracle.dense_power_frames(x, n_fft, hop)
+    fb = oracle.mel_filterbank(48000, n_fft, 40).astype(np.float64)
+    for c in range(C):
+        e, frac = elementwise_rel(P[c], ref[c])
+        assert e < RTOL and frac > 0.5, (c, e, frac)
+        mref = ref[c] @ fb.T
+        assert (np.abs(mel[c] - mref) / mref).max() < RTOL
+
+
+@pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 5), (256, 64, 2), (512, 128, 3), (4096, 1024, 2)])
+def test_classifier_epilogue_is_bit_identical_to_the_separate_kernels(data, n_fft, hop, C):
+    """ofp_stft_power_mel_mlp: power, mel and logits out of ONE kernel equal, bit for bit, what
+    ofp_stft_power_mel followed by the FCNN gives -- for every frame count that leaves a partly
+    filled 16-row tile, with and without the power / mel outputs."""
+    from onset_fingerprinting_amd.data import MelBank, stft_power_mel_dense, stft_power_mel_mlp_dense
+    from onset_fingerprinting_amd.pipeline import seeded_fcnn
+    rng = np.random.default_rng(n_fft + 7)
+    mb = MelBank(48000, n_fft, 40)
+    m = seeded_fcnn(40, 8)
+    mlp = m.device_mlp(0)
+    for H in (1, 17, 203):
+        N = n_fft + (H - 1) * hop + 3
+        x = torch.from_numpy((rng.standard_normal((2, N, C)) * np.exp(rng.uniform(-5, 0, (2, 1, C)))).astype(np.float32)).cuda()
+        P0, mel0 = stft_power_mel_dense(x, n_fft, hop, mb)
+        log0 = m.forward_layerwise(mel0.reshape(-1, 40)).reshape(2, C, H, 8)
+        P1, mel1, log1 = stft_power_mel_mlp_dense(x, n_fft, hop, mb, mlp, want_power=True, want_mel=True)
+        assert torch.equal(P0, P1) and torch.equal(mel0, mel1)
+        assert np.array_equal(log0.cpu().numpy().view(np.uint32), log1.cpu().numpy().view(np.uint32)), (n_fft, H)
+        _, _, log2 = stft_power_mel_mlp_dense(x, n_fft, hop, mb, mlp, want_power=False, want_mel=False)
+        assert torch.equal(log1, log2)
+
+
 def test_dense_power_linearity_and_parseval_at_scale(data):
     """Size-independent properties on a large input (full C2 size is covered by
     bench.py's own check): Parseval against the windowed frame energy."""
