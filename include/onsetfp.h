@@ -307,6 +307,47 @@ int ofp_groupnorm1(const float* d_x, int64_t n, int32_t K, int32_t V, const floa
  * full auto-correlation of every map, summed over the K maps, soft-maxed over the lags. */
 int ofp_autocorr_softmax(const float* d_x, int64_t n, int32_t K, int32_t V, float* d_out, void* stream);
 
+/* ---- per-hop streaming session (BASELINE config 5) -------------------------------------------
+ * The reference's realtime pattern -- PortAudio callback: ring-buffer write (realtime/audio.py:97),
+ * AmplitudeOnsetDetector on the hop (:62-74), classifier (multilateration.py:555-557 ->
+ * calibration.py:552-560), one spectral frame of the trailing n_fft samples per hop
+ * (realtime/recording.py:273-280) -- as ONE hipGraph per hop, captured at creation:
+ *   H2D hop -> detector (state in HBM) -> per channel: ring write, Hann x audio[-n_fft:], rFFT,
+ *   |X|^2, mel bands, FCNN -> D2H of {count, records, logits, mel, rel}.
+ * The ring buffer ([ring_samples][C] float32, zeros at start: realtime/config.py:45,59) and all
+ * detector state stay on the device.  The detector handle is borrowed and must outlive the session;
+ * hop length and channel count are the detector's block_size and n_channels.  All h_ pointers are
+ * HOST memory.  One hop may be in flight per session (submit -> collect; push = both). */
+typedef struct ofp_hop_config {
+    int32_t n_fft;          /* 256, 512, 1024, 2048 or 4096; periodic Hann of n_fft (data.py:627) */
+    int64_t ring_samples;   /* rows of the ring buffer, >= max(n_fft, block_size) */
+    int32_t n_mels;         /* mel filterbank, band-CSR as for ofp_mel; HOST arrays, copied */
+    const int32_t* fb_lo;
+    const int32_t* fb_len;
+    const int32_t* fb_off;
+    const float* fb_w;
+    int32_t fb_nnz;
+    const ofp_mlp* mlp;     /* classifier on the n_mels bands, or NULL; parameters are copied */
+    int32_t want_rel;       /* != 0: the hop's relative envelope [B][C] is copied back too */
+} ofp_hop_config;
+typedef struct ofp_hop_session ofp_hop_session; /* opaque */
+int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session** out);
+int ofp_hop_destroy(ofp_hop_session* s);
+/* back to the state after creation (zero ring, fresh detector state, hop counter 0) */
+int ofp_hop_reset(ofp_hop_session* s);
+/* AmplitudeOnsetDetector.init_minmax_tracker (detection.py:827-840) over h_x [n_rows][C] */
+int ofp_hop_warmup(ofp_hop_session* s, const float* h_x, int64_t n_rows);
+/* One hop, h_hop [B][C].  Outputs (each may be NULL): *n_onsets; h_records [C] with .sample =
+ * hop_index * B + delta (audio.py:65) and .clip = 0, in channel order; h_logits [C][mlp outputs];
+ * h_mel [C][n_mels]; h_rel [B][C] (needs want_rel). */
+int ofp_hop_submit(ofp_hop_session* s, const float* h_hop);
+int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records, float* h_logits, float* h_mel,
+                    float* h_rel);
+int ofp_hop_push(ofp_hop_session* s, const float* h_hop, int64_t* n_onsets, ofp_onset* h_records, float* h_logits,
+                 float* h_mel, float* h_rel);
+/* audio[-n_rows:] of the ring buffer (oldest row first), h_out [n_rows][C]; n_rows <= ring_samples */
+int ofp_hop_ring_read(ofp_hop_session* s, int64_t n_rows, float* h_out);
+
 /* ---- onset groups and their windows --------------------------------
  * find_onset_groups (detection.py:131-189) per clip, straight from the records
  * ofp_detect_offline wrote, without a host round trip.

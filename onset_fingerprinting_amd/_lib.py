@@ -57,6 +57,21 @@ class DetectTuning(ctypes.Structure):
     ]
 
 
+class HopConfig(ctypes.Structure):
+    _fields_ = [
+        ("n_fft", ctypes.c_int32),
+        ("ring_samples", ctypes.c_int64),
+        ("n_mels", ctypes.c_int32),
+        ("fb_lo", ctypes.c_void_p),
+        ("fb_len", ctypes.c_void_p),
+        ("fb_off", ctypes.c_void_p),
+        ("fb_w", ctypes.c_void_p),
+        ("fb_nnz", ctypes.c_int32),
+        ("mlp", ctypes.c_void_p),
+        ("want_rel", ctypes.c_int32),
+    ]
+
+
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _f32p_h = ctypes.POINTER(ctypes.c_float)
 _long_p = ctypes.POINTER(ctypes.c_long)
@@ -109,6 +124,14 @@ SIGNATURES = {
     "ofp_mlp_forward": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ofp_stft_power_mel_mlp": (ctypes.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
                                               _vp, _i64, _vp, _vp, _vp]),
+    "ofp_hop_create": (ctypes.c_int, [_vp, ctypes.POINTER(HopConfig), ctypes.POINTER(_vp)]),
+    "ofp_hop_destroy": (ctypes.c_int, [_vp]),
+    "ofp_hop_reset": (ctypes.c_int, [_vp]),
+    "ofp_hop_warmup": (ctypes.c_int, [_vp, _vp, _i64]),
+    "ofp_hop_submit": (ctypes.c_int, [_vp, _vp]),
+    "ofp_hop_collect": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
+    "ofp_hop_push": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
+    "ofp_hop_ring_read": (ctypes.c_int, [_vp, _i64, _vp]),
     "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                                   _i32, _vp, _vp]),

@@ -1,0 +1,475 @@
+// Per-hop streaming session (BASELINE config 5): the reference's realtime call pattern
+//
+//   PortAudio callback (realtime/audio.py:81-120): ring-buffer write (:97) -> AmplitudeOnsetDetector
+//   on the hop (:62-74, detection.py:727-798) -> classifier (multilateration.py:555-557 ->
+//   calibration.py:552-560), and the per-hop spectral frame of the trailing n_fft samples
+//   (realtime/recording.py:273-280)
+//
+// as ONE captured hipGraph per hop on a device-resident ring buffer:
+//
+//   H2D of the hop (B x C floats, pinned)  ->  k_hop_begin (hop counter, onset count = 0)
+//   ->  k_stream (the detector, csrc/ofp_stream.hip: state in HBM)
+//   ->  k_hop_spectral (one workgroup per channel: ring write, Hann x trailing n_fft samples,
+//       rFFT, |X|^2, mel bands, the whole FCNN -- nothing but mel + logits leaves the chip)
+//   ->  D2H of one packed result block {count, records, logits, mel, rel}.
+//
+// A replay needs no argument update: the write cursor is a counter in device memory.  The frame the
+// spectral kernel computes for the hop that ends at sample e is bit-identical to frame (e - n_fft)/B
+// of the dense kernel (k_stft_power, hop = B) on the same stream: same tables, same FFT, same mel
+// and classifier epilogue.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ofp_detector.h"
+#include "ofp_fft.h"
+#include "ofp_mlp.h"
+
+using namespace ofpfft;
+
+namespace {
+
+struct HopArgs {
+    int C, B, n_mels, nnz, mean_mode;
+    int64_t R;             // rows of the ring buffer
+    int64_t* ctl;          // [0] hops pushed so far (incremented by k_hop_begin), [1] spare
+    const float* hop;      // [B][C] the hop just uploaded
+    float* ring;           // [R][C]
+    const float2* twM;     // precomputed once per session by k_hop_tables (the same values
+    const float2* twF;     // k_stft_power builds in LDS)
+    const float* win;
+    const int32_t *flo, *flen, *foff;
+    const float* fw;
+    MlpPlan plan;          // n_layers == 0: no classifier
+    float* logits;         // [C][n_out]
+    float* mel;            // [C][n_mels]
+    int64_t* count;        // onset count of the hop (zeroed by k_hop_begin)
+    int64_t* hop_index;    // result header: index of the hop this block belongs to
+};
+
+__global__ void k_hop_begin(HopArgs a) {
+    if (threadIdx.x == 0) {
+        const int64_t h = a.ctl[0];
+        a.ctl[0] = h + 1;
+        *a.count = 0;
+        *a.hop_index = h;
+    }
+}
+
+template <int F>
+__global__ void k_hop_tables(float2* twM, float2* twF, float* win) {
+    build_tables<F>(twM, twF, win, F);
+}
+
+template <int F>
+struct HopCfg {
+    static constexpr int M = F / 2;
+    static constexpr int T = Cfg<F>::T;
+    static constexpr int WGS = T < 64 ? 64 : T;
+};
+
+template <int F>
+__global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
+    constexpr int M = HopCfg<F>::M, T = HopCfg<F>::T, WGS = HopCfg<F>::WGS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* twM = reinterpret_cast<float2*>(smem);
+    float2* twF = twM + M;
+    float* win = reinterpret_cast<float*>(twF + M + 2);
+    float2* A = reinterpret_cast<float2*>(win + F);
+    float* fw = reinterpret_cast<float*>(A + M);
+    int32_t* flo = reinterpret_cast<int32_t*>(fw + a.nnz);
+    int32_t* flen = flo + a.n_mels;
+    int32_t* foff = flen + a.n_mels;
+    float* mprm = reinterpret_cast<float*>(foff + a.n_mels);
+    float* tileA = mprm + ((a.plan.n_params + 3) & ~3);
+    float* tileB = tileA + 16 * a.plan.st_a;
+    const int c = blockIdx.x, C = a.C, B = a.B;
+    const int tid = threadIdx.x;
+    // tables, filterbank and classifier parameters: L2-resident copies -> LDS
+    for (int k = tid; k < M; k += WGS) twM[k] = a.twM[k];
+    for (int k = tid; k <= M; k += WGS) twF[k] = a.twF[k];
+    for (int n = tid; n < F; n += WGS) win[n] = a.win[n];
+    for (int i = tid; i < a.nnz; i += WGS) fw[i] = a.fw[i];
+    for (int i = tid; i < a.n_mels; i += WGS) {
+        flo[i] = a.flo[i];
+        flen[i] = a.flen[i];
+        foff[i] = a.foff[i];
+    }
+    for (int i = tid; i < a.plan.n_params; i += WGS) mprm[i] = a.plan.params[i];
+    if (a.plan.n_layers > 0)
+        for (int i = tid; i < 16 * a.plan.st_a; i += WGS) tileA[i] = 0.0f;
+    const int64_t h = a.ctl[0];      // hops pushed including this one
+    const int64_t first = (h - 1) * B;  // stream index of this hop's first sample
+    // ring-buffer write of this channel's column (realtime/audio.py:97)
+    for (int t = tid; t < B; t += WGS) a.ring[((first + t) % a.R) * C + c] = a.hop[(int64_t)t * C + c];
+    // trailing n_fft samples of the stream (realtime/recording.py:276: audio[-n_fft:]); samples before
+    // the stream started read as the zeros the ring was created with
+    const int64_t base = h * B - F;
+    auto sample = [&](int64_t s) -> float {
+        if (s < 0) return 0.0f;
+        if (s >= first) return a.hop[(s - first) * C + c];
+        return a.ring[(s % a.R) * C + c];
+    };
+    for (int p = tid; p < M; p += WGS)
+        A[p] = make_float2(sample(base + 2 * p) * win[2 * p], sample(base + 2 * p + 1) * win[2 * p + 1]);
+    __syncthreads();
+    constexpr int NK = M / T + 1;
+    float pk[NK];
+    if (tid < T) {
+        cfft<M, T>(A, twM, tid);
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = tid + q * T;
+            pk[q] = 0.0f;
+            if (k <= M) {
+                const float2 X = rfft_bin<M>(A, twF, k);
+                pk[q] = X.x * X.x + X.y * X.y;
+            }
+        }
+        frame_sync<T>();  // every bin of the spectrum has been read
+        float* pf = reinterpret_cast<float*>(A);
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+            if (tid + q * T <= M) pf[tid + q * T] = pk[q];
+        frame_sync<T>();
+        for (int b = tid; b < a.n_mels; b += T) {  // same summation order as k_mel / k_stft_power
+            const float* p = pf + flo[b];
+            const float* wb = fw + foff[b];
+            float acc = 0.0f;
+            const int nb_ = flen[b];
+#pragma unroll 4
+            for (int k = 0; k < nb_; ++k) acc = fmaf(p[k], wb[k], acc);
+            a.mel[c * a.n_mels + b] = acc;
+            if (a.plan.n_layers > 0) tileA[b] = acc;  // row 0 of the classifier's tile
+        }
+    }
+    if (a.plan.n_layers > 0) {
+        __syncthreads();
+        if (tid < 64) {
+            const int nout = a.plan.dims[a.plan.n_layers];
+            ofp_mlp_tile(a.plan, mprm, tileA, tileB, tid, [&](int r, int col, float v) {
+                if (r == 0) a.logits[c * nout + col] = v;
+            });
+        }
+    }
+}
+
+}  // namespace
+
+struct ofp_hop_session {
+    ofp_detector* det = nullptr;
+    int C = 0, B = 0, n_fft = 0, n_mels = 0, n_out = 0, want_rel = 0;
+    int64_t R = 0;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void* d_state = nullptr;
+    float* d_hop = nullptr;
+    float* d_ring = nullptr;
+    int64_t* d_ctl = nullptr;
+    float2* d_twM = nullptr;
+    float2* d_twF = nullptr;
+    float* d_win = nullptr;
+    int32_t* d_fb_i = nullptr;  // lo | len | off
+    float* d_fb_w = nullptr;
+    float* d_prm = nullptr;     // own copy of the classifier's parameters
+    unsigned char* d_res = nullptr;
+    float* h_hop = nullptr;           // pinned
+    unsigned char* h_res = nullptr;   // pinned
+    // result block layout (bytes)
+    int64_t o_count = 0, o_index = 8, o_rec = 16, o_logits = 0, o_mel = 0, o_rel = 0, res_bytes = 0;
+    HopArgs args;
+    size_t lds = 0;
+    int64_t pushed = 0;   // hops submitted
+    bool in_flight = false;
+};
+
+namespace {
+
+template <int F>
+int hop_tables(ofp_hop_session* s) {
+    hipLaunchKernelGGL(k_hop_tables<F>, dim3(1), dim3(256), 0, s->stream, s->d_twM, s->d_twF, s->d_win);
+    OFP_LAUNCH_CHECK("k_hop_tables");
+    return OFP_OK;
+}
+
+template <int F>
+int hop_spectral(ofp_hop_session* s) {
+    if (s->lds > 65536)
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hop_spectral<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds));
+    hipLaunchKernelGGL(k_hop_spectral<F>, dim3((unsigned)s->C), dim3(HopCfg<F>::WGS), s->lds, s->stream, s->args);
+    OFP_LAUNCH_CHECK("k_hop_spectral");
+    return OFP_OK;
+}
+
+int dispatch_tables(ofp_hop_session* s) {
+    switch (s->n_fft) {
+        case 256: return hop_tables<256>(s);
+        case 512: return hop_tables<512>(s);
+        case 1024: return hop_tables<1024>(s);
+        case 2048: return hop_tables<2048>(s);
+        case 4096: return hop_tables<4096>(s);
+    }
+    return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", s->n_fft);
+}
+
+int dispatch_spectral(ofp_hop_session* s) {
+    switch (s->n_fft) {
+        case 256: return hop_spectral<256>(s);
+        case 512: return hop_spectral<512>(s);
+        case 1024: return hop_spectral<1024>(s);
+        case 2048: return hop_spectral<2048>(s);
+        case 4096: return hop_spectral<4096>(s);
+    }
+    return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", s->n_fft);
+}
+
+// the per-hop sequence, enqueued on the session's stream (captured once, then replayed)
+int enqueue_hop(ofp_hop_session* s) {
+    OFP_HIP(hipMemcpyAsync(s->d_hop, s->h_hop, (size_t)s->B * s->C * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_hop_begin, dim3(1), dim3(64), 0, s->stream, s->args);
+    OFP_LAUNCH_CHECK("k_hop_begin");
+    int rc = ofp_stream_process(s->det, s->d_state, s->d_hop, 1, 0, 0, 0,
+                                s->want_rel ? reinterpret_cast<float*>(s->d_res + s->o_rel) : nullptr,
+                                reinterpret_cast<ofp_onset*>(s->d_res + s->o_rec), s->C,
+                                reinterpret_cast<int64_t*>(s->d_res + s->o_count), s->stream);
+    if (rc != OFP_OK) return rc;
+    rc = dispatch_spectral(s);
+    if (rc != OFP_OK) return rc;
+    OFP_HIP(hipMemcpyAsync(s->h_res, s->d_res, (size_t)s->res_bytes, hipMemcpyDeviceToHost, s->stream));
+    return OFP_OK;
+}
+
+int reset_state(ofp_hop_session* s) {
+    int rc = ofp_stream_state_init(s->det, s->d_state, s->stream);
+    if (rc != OFP_OK) return rc;
+    OFP_HIP(hipMemsetAsync(s->d_ring, 0, (size_t)s->R * s->C * sizeof(float), s->stream));
+    OFP_HIP(hipMemsetAsync(s->d_ctl, 0, 2 * sizeof(int64_t), s->stream));
+    OFP_HIP(hipMemsetAsync(s->d_res, 0, (size_t)s->res_bytes, s->stream));
+    OFP_HIP(hipStreamSynchronize(s->stream));
+    s->pushed = 0;
+    s->in_flight = false;
+    return OFP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofp_hop_destroy(ofp_hop_session* s) {
+    if (!s) return OFP_OK;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    void* dev[] = {s->d_state, s->d_hop, s->d_ring, s->d_ctl, s->d_twM, s->d_twF, s->d_win, s->d_fb_i, s->d_fb_w,
+                   s->d_prm, s->d_res};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (s->h_hop) (void)hipHostFree(s->h_hop);
+    if (s->h_res) (void)hipHostFree(s->h_res);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return OFP_OK;
+}
+
+int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session** out) {
+    OFP_REQUIRE(det && cfg && out, "ofp_hop_create: NULL argument");
+    const int C = det->p.n_channels, B = det->p.block_size;
+    OFP_REQUIRE(C <= 1024, "ofp_hop_create: at most 1024 channels (got %d)", C);
+    OFP_REQUIRE(cfg->n_fft == 256 || cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048 || cfg->n_fft == 4096,
+                "n_fft %d not supported (256,512,1024,2048,4096)", cfg->n_fft);
+    OFP_REQUIRE(cfg->ring_samples >= cfg->n_fft && cfg->ring_samples >= B,
+                "ofp_hop_create: the ring buffer (%lld rows) must hold n_fft = %d and one hop = %d samples",
+                (long long)cfg->ring_samples, cfg->n_fft, B);
+    OFP_REQUIRE(cfg->n_mels >= 1 && cfg->fb_lo && cfg->fb_len && cfg->fb_off && cfg->fb_w && cfg->fb_nnz >= 1,
+                "ofp_hop_create: NULL / empty filterbank");
+    OFP_REQUIRE(cfg->fb_nnz <= 4 * (cfg->n_fft / 2 + 1), "ofp_hop_create: filterbank with %d weights for %d bins",
+                cfg->fb_nnz, cfg->n_fft / 2 + 1);
+    OFP_REQUIRE(!cfg->mlp || cfg->mlp->plan.dims[0] == cfg->n_mels,
+                "ofp_hop_create: the classifier takes %d inputs, the filterbank has %d bands",
+                cfg->mlp ? cfg->mlp->plan.dims[0] : 0, cfg->n_mels);
+    ofp_hop_session* s = new (std::nothrow) ofp_hop_session();
+    if (!s) return ofp::fail(OFP_ERR_INVALID, "out of host memory");
+    s->det = det;
+    s->C = C;
+    s->B = B;
+    s->n_fft = cfg->n_fft;
+    s->n_mels = cfg->n_mels;
+    s->R = cfg->ring_samples;
+    s->want_rel = cfg->want_rel ? 1 : 0;
+    MlpPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    if (cfg->mlp) plan = cfg->mlp->plan;
+    s->n_out = cfg->mlp ? plan.dims[plan.n_layers] : 0;
+    auto up8 = [](int64_t v) { return (v + 7) / 8 * 8; };
+    s->o_logits = up8(s->o_rec + (int64_t)C * (int64_t)sizeof(ofp_onset));
+    s->o_mel = up8(s->o_logits + (int64_t)C * s->n_out * 4);
+    s->o_rel = up8(s->o_mel + (int64_t)C * s->n_mels * 4);
+    s->res_bytes = up8(s->o_rel + (s->want_rel ? (int64_t)B * C * 4 : 0));
+    const int M = s->n_fft / 2;
+    const int st_a = cfg->mlp ? plan.st_a : 0, st_b = cfg->mlp ? plan.st_b : 0;
+    s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)M * 8 + (size_t)cfg->fb_nnz * 4 +
+             (size_t)3 * s->n_mels * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + 64;
+    int rc = OFP_OK;
+    auto fail = [&](int code) {
+        ofp_hop_destroy(s);
+        return code;
+    };
+    if (s->lds > 160 * 1024) {
+        ofp_hop_destroy(s);
+        return ofp::fail(OFP_ERR_INVALID, "ofp_hop_create: %zu bytes of LDS needed, 160 KiB available", s->lds);
+    }
+#define HOP_TRY(call)                                                                                           \
+    do {                                                                                                        \
+        hipError_t e__ = (call);                                                                                \
+        if (e__ != hipSuccess) {                                                                                \
+            ofp_hop_destroy(s);                                                                                 \
+            return ofp::fail(OFP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__));                      \
+        }                                                                                                       \
+    } while (0)
+    HOP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const int64_t sb = ofp_stream_state_bytes(det);
+    HOP_TRY(hipMalloc(&s->d_state, (size_t)sb));
+    HOP_TRY(hipMalloc(&s->d_hop, (size_t)B * C * 4));
+    HOP_TRY(hipMalloc(&s->d_ring, (size_t)s->R * C * 4));
+    HOP_TRY(hipMalloc(&s->d_ctl, 16));
+    HOP_TRY(hipMalloc(&s->d_twM, (size_t)M * 8));
+    HOP_TRY(hipMalloc(&s->d_twF, (size_t)(M + 2) * 8));
+    HOP_TRY(hipMalloc(&s->d_win, (size_t)s->n_fft * 4));
+    HOP_TRY(hipMalloc(&s->d_fb_i, (size_t)3 * s->n_mels * 4));
+    HOP_TRY(hipMalloc(&s->d_fb_w, (size_t)cfg->fb_nnz * 4));
+    HOP_TRY(hipMalloc(&s->d_res, (size_t)s->res_bytes));
+    HOP_TRY(hipHostMalloc((void**)&s->h_hop, (size_t)B * C * 4, hipHostMallocDefault));
+    HOP_TRY(hipHostMalloc((void**)&s->h_res, (size_t)s->res_bytes, hipHostMallocDefault));
+    std::memset(s->h_res, 0, (size_t)s->res_bytes);
+    std::memset(s->h_hop, 0, (size_t)B * C * 4);
+    HOP_TRY(hipMemcpy(s->d_fb_i, cfg->fb_lo, (size_t)s->n_mels * 4, hipMemcpyHostToDevice));
+    HOP_TRY(hipMemcpy(s->d_fb_i + s->n_mels, cfg->fb_len, (size_t)s->n_mels * 4, hipMemcpyHostToDevice));
+    HOP_TRY(hipMemcpy(s->d_fb_i + 2 * s->n_mels, cfg->fb_off, (size_t)s->n_mels * 4, hipMemcpyHostToDevice));
+    HOP_TRY(hipMemcpy(s->d_fb_w, cfg->fb_w, (size_t)cfg->fb_nnz * 4, hipMemcpyHostToDevice));
+    if (cfg->mlp) {  // the session keeps its own copy: the handle may be destroyed afterwards
+        HOP_TRY(hipMalloc(&s->d_prm, (size_t)plan.n_params * 4));
+        HOP_TRY(hipMemcpy(s->d_prm, cfg->mlp->d_params, (size_t)plan.n_params * 4, hipMemcpyDeviceToDevice));
+        plan.params = s->d_prm;
+    }
+    HopArgs& a = s->args;
+    std::memset(&a, 0, sizeof(a));
+    a.C = C;
+    a.B = B;
+    a.n_mels = s->n_mels;
+    a.nnz = cfg->fb_nnz;
+    a.R = s->R;
+    a.ctl = s->d_ctl;
+    a.hop = s->d_hop;
+    a.ring = s->d_ring;
+    a.twM = s->d_twM;
+    a.twF = s->d_twF;
+    a.win = s->d_win;
+    a.flo = s->d_fb_i;
+    a.flen = s->d_fb_i + s->n_mels;
+    a.foff = s->d_fb_i + 2 * s->n_mels;
+    a.fw = s->d_fb_w;
+    a.plan = plan;
+    a.logits = reinterpret_cast<float*>(s->d_res + s->o_logits);
+    a.mel = reinterpret_cast<float*>(s->d_res + s->o_mel);
+    a.count = reinterpret_cast<int64_t*>(s->d_res + s->o_count);
+    a.hop_index = reinterpret_cast<int64_t*>(s->d_res + s->o_index);
+    if ((rc = dispatch_tables(s)) != OFP_OK) return fail(rc);
+    // one un-captured pass over zeros loads every code object and sets the kernel attributes
+    // (neither may happen during capture), then the state is reset and the sequence captured
+    if ((rc = reset_state(s)) != OFP_OK) return fail(rc);
+    if ((rc = enqueue_hop(s)) != OFP_OK) return fail(rc);
+    HOP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = reset_state(s)) != OFP_OK) return fail(rc);
+    HOP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_hop(s);
+    hipError_t ce = hipStreamEndCapture(s->stream, &s->graph);
+    if (rc != OFP_OK) return fail(rc);
+    HOP_TRY(ce);
+    HOP_TRY(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+#undef HOP_TRY
+    *out = s;
+    return OFP_OK;
+}
+
+int ofp_hop_reset(ofp_hop_session* s) {
+    OFP_REQUIRE(s, "ofp_hop_reset: NULL session");
+    return reset_state(s);
+}
+
+int ofp_hop_warmup(ofp_hop_session* s, const float* h_x, int64_t n_rows) {
+    OFP_REQUIRE(s && (h_x || n_rows == 0), "ofp_hop_warmup: NULL argument");
+    OFP_REQUIRE(!s->in_flight, "ofp_hop_warmup: a hop is in flight (collect it first)");
+    if (n_rows <= 0) return OFP_OK;
+    float* d = nullptr;
+    OFP_HIP(hipMalloc(&d, (size_t)n_rows * s->C * 4));
+    hipError_t e = hipMemcpyAsync(d, h_x, (size_t)n_rows * s->C * 4, hipMemcpyHostToDevice, s->stream);
+    int rc = e == hipSuccess ? ofp_stream_process(s->det, s->d_state, d, 0, n_rows, 1, 0, nullptr, nullptr, 0, nullptr,
+                                                  s->stream)
+                             : ofp::fail(OFP_ERR_HIP, "ofp_hop_warmup: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int ofp_hop_submit(ofp_hop_session* s, const float* h_hop) {
+    OFP_REQUIRE(s && h_hop, "ofp_hop_submit: NULL argument");
+    OFP_REQUIRE(!s->in_flight, "ofp_hop_submit: the previous hop has not been collected");
+    std::memcpy(s->h_hop, h_hop, (size_t)s->B * s->C * sizeof(float));
+    OFP_HIP(hipGraphLaunch(s->exec, s->stream));
+    s->in_flight = true;
+    s->pushed += 1;
+    return OFP_OK;
+}
+
+int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records, float* h_logits, float* h_mel,
+                    float* h_rel) {
+    OFP_REQUIRE(s, "ofp_hop_collect: NULL session");
+    OFP_REQUIRE(s->in_flight, "ofp_hop_collect: no hop in flight");
+    OFP_HIP(hipStreamSynchronize(s->stream));
+    s->in_flight = false;
+    const unsigned char* r = s->h_res;
+    int64_t count, index;
+    std::memcpy(&count, r + s->o_count, 8);
+    std::memcpy(&index, r + s->o_index, 8);
+    if (index != s->pushed - 1)
+        return ofp::fail(OFP_ERR_HIP, "ofp_hop_collect: result block of hop %lld, expected %lld", (long long)index,
+                         (long long)(s->pushed - 1));
+    if (n_onsets) *n_onsets = count;
+    if (h_records) {
+        const int64_t n = count < s->C ? count : s->C;
+        std::memcpy(h_records, r + s->o_rec, (size_t)n * sizeof(ofp_onset));
+        for (int64_t i = 0; i < n; ++i) h_records[i].sample += index * s->B;  // audio.py:65: current_index + delta
+    }
+    if (h_logits && s->n_out) std::memcpy(h_logits, r + s->o_logits, (size_t)s->C * s->n_out * 4);
+    if (h_mel) std::memcpy(h_mel, r + s->o_mel, (size_t)s->C * s->n_mels * 4);
+    if (h_rel && s->want_rel) std::memcpy(h_rel, r + s->o_rel, (size_t)s->B * s->C * 4);
+    return OFP_OK;
+}
+
+int ofp_hop_push(ofp_hop_session* s, const float* h_hop, int64_t* n_onsets, ofp_onset* h_records, float* h_logits,
+                 float* h_mel, float* h_rel) {
+    int rc = ofp_hop_submit(s, h_hop);
+    if (rc != OFP_OK) return rc;
+    return ofp_hop_collect(s, n_onsets, h_records, h_logits, h_mel, h_rel);
+}
+
+int ofp_hop_ring_read(ofp_hop_session* s, int64_t n_rows, float* h_out) {
+    OFP_REQUIRE(s && h_out && n_rows >= 0 && n_rows <= s->R, "ofp_hop_ring_read: bad argument");
+    OFP_REQUIRE(!s->in_flight, "ofp_hop_ring_read: a hop is in flight (collect it first)");
+    // audio[-n_rows:] of the reference's CircularArray: the rows ending at the write cursor, oldest first
+    const int64_t end = s->pushed * s->B;
+    const size_t row = (size_t)s->C * 4;
+    for (int64_t done = 0; done < n_rows;) {
+        const int64_t t = end - n_rows + done;
+        const int64_t p = ((t % s->R) + s->R) % s->R;
+        const int64_t run = std::min<int64_t>(n_rows - done, s->R - p);
+        OFP_HIP(hipMemcpy(h_out + done * s->C, reinterpret_cast<char*>(s->d_ring) + p * row, (size_t)run * row,
+                          hipMemcpyDeviceToHost));
+        done += run;
+    }
+    return OFP_OK;
+}
+
+}  // extern "C"

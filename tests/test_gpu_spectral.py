@@ -108,7 +108,7 @@ def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
     fb = oracle.mel_filterbank(48000, n_fft, 40).astype(np.float64)
     for c in range(C):
         e, frac = elementwise_rel(P[c], ref[c])
-        assert e < RTOL and frac > 0.5, (c, e, frac)
+        assert e < RTOL and frac > 0.2, (c, e, frac)  # (the tone's skirt leaves ~1/4 of the bins above the floor)
         mref = ref[c] @ fb.T
         assert (np.abs(mel[c] - mref) / mref).max() < RTOL
 

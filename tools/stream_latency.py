@@ -1,6 +1,17 @@
-"""BASELINE config 5: 2-ch 48 kHz stream, per-hop detect in a captured hipGraph.
-Per hop: H2D of hop x C samples (pinned) -> k_stream -> D2H of the onset count.
-Prints p50 / p99 latency per hop over N hops as one JSON line."""
+"""BASELINE config 5: per-hop latency of the WHOLE captured graph (H2D hop -> detector -> ring write +
+trailing-frame rFFT + mel + fused FCNN -> D2H of {count, records, logits, mel}) through ofp_hop_push.
+
+    python tools/stream_latency.py [--config c5|realtime] [--hops N]
+
+  c5        2 ch @ 48 kHz, hop 256, n_fft 1024, default detector arguments (BASELINE.json configs[4])
+  realtime  3 ch @ 96 kHz, hop 128, n_fft 2048, the detector arguments of realtime/audio.py:39-52
+            (realtime/config.py:15,24,36,53)
+
+Latency = wall time of one ofp_hop_push call (host copy into the pinned hop buffer, graph launch,
+stream synchronise, copy-out of the result block), measured around the ctypes call.  Prints one JSON
+line; the onsets of the replay are checked against a second, untimed replay after a reset (the
+timing loop must not disturb the result)."""
+import argparse
 import json
 import sys
 import time
@@ -8,37 +19,48 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
-from onset_fingerprinting_amd import detection, synth  # noqa: E402
+from onset_fingerprinting_amd import realtime, synth  # noqa: E402
+from onset_fingerprinting_amd.pipeline import seeded_fcnn  # noqa: E402
 
-SR, C = 48000, 2
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-hops = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-x = synth.drum_hits(C, hops * B / SR + 0.1, SR, seed=4, period=0.31)
-od = detection.AmplitudeOnsetDetector(C, B, sr=SR)
-od.init_minmax_tracker(x[: int(0.5 * SR)])
-host = torch.from_numpy(x[: hops * B].reshape(hops, B, C)).pin_memory()
-hop_in = torch.empty((B, C), dtype=torch.float32, device="cuda")
-rec = torch.empty((hops * C, 16), dtype=torch.uint8, device="cuda")
-cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-cnt_host = torch.zeros(1, dtype=torch.int64).pin_memory()
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    od.process(hop_in, 1, 0, None, rec, cnt)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s):
-        od.process(hop_in, 1, 0, None, rec, cnt)
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c5", choices=["c5", "realtime"])
+ap.add_argument("--hops", type=int, default=10000)
+ap.add_argument("--no-classifier", action="store_true")
+args = ap.parse_args()
+if args.config == "c5":
+    C, B, SR, F, kw = 2, 256, 48000, 1024, {}
+else:
+    C, B, SR, F, kw = 3, 128, 96000, 2048, dict(realtime.REALTIME_DETECTOR_KWARGS)
+hops = args.hops
+x = synth.drum_hits(C, hops * B / SR + 0.6, SR, seed=4, period=0.31)
+clf = None if args.no_classifier else seeded_fcnn(40, 8)
+sess = realtime.HopSession(C, B, sr=SR, n_fft=F, n_mels=40, classifier=clf, **kw)
+blocks = np.ascontiguousarray(x[: hops * B].reshape(hops, B, C))
+
+
+def run(timed):
+    sess.reset()
+    sess.init_minmax_tracker(x[: int(0.5 * SR)])
     lat = np.empty(hops)
+    onsets = 0
     for i in range(hops):
         t0 = time.perf_counter()
-        hop_in.copy_(host[i], non_blocking=True)
-        g.replay()
-        cnt_host.copy_(cnt, non_blocking=True)
-        s.synchronize()
+        onsets += sess.push_raw(blocks[i])
         lat[i] = time.perf_counter() - t0
-print(json.dumps({"config": f"C5 streaming: {C} ch @ {SR} Hz, hop {B}, hipGraph per hop (H2D hop + k_stream + D2H count)",
-                  "hops": hops, "p50_us": float(np.percentile(lat, 50) * 1e6),
-                  "p99_us": float(np.percentile(lat, 99) * 1e6), "mean_us": float(lat.mean() * 1e6),
-                  "hop_budget_us": B / SR * 1e6, "onsets": int(cnt_host.item())}))
+    return lat, onsets
+
+
+run(False)  # warm: first-touch of every buffer, clocks up
+lat, onsets = run(True)
+_, onsets2 = run(False)
+assert onsets == onsets2 and onsets > 0, (onsets, onsets2)
+print(json.dumps({
+    "config": f"{args.config}: {C} ch @ {SR} Hz, hop {B}, n_fft {F}, 40 mel, "
+              f"{'FCNN(40-10-10-10-8)' if clf is not None else 'no classifier'}; one hipGraph per hop "
+              "(H2D hop + k_hop_begin + k_stream + k_hop_spectral + D2H result block), ring buffer "
+              f"{sess.ring_samples} rows on the device",
+    "detector_kwargs": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()} or "reference defaults",
+    "hops": hops, "p50_us": float(np.percentile(lat, 50) * 1e6), "p90_us": float(np.percentile(lat, 90) * 1e6),
+    "p99_us": float(np.percentile(lat, 99) * 1e6), "max_us": float(lat.max() * 1e6), "mean_us": float(lat.mean() * 1e6),
+    "hop_budget_us": B / SR * 1e6, "onsets": int(onsets)}))
