@@ -92,8 +92,9 @@ def elementwise_rel(got, ref, floor_frac=1e-6):
 def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
     """north_star: "1e-4 relative fp32" -- ELEMENT-wise, not only norm-wise: every power bin that is at
     least 1e-6 of the largest bin of its channel (an fp32 FFT's error floor is ~1e-7 of the largest
-    bin, so smaller bins carry no relative accuracy in the reference's complex64 either) and EVERY mel
-    band (sums of non-negative terms, no cancellation) within 1e-4 of the fp64 oracle."""
+    bin, so smaller bins carry no relative accuracy in an fp32 transform) and every mel band that is at
+    least 1e-6 of the largest band (sums of non-negative terms: no cancellation beyond the bins' own
+    error floor) within 1e-4 of the fp64 oracle."""
     from onset_fingerprinting_amd.data import MelBank, stft_power_mel_dense
     rng = np.random.default_rng(n_fft + 1)
     N = n_fft * 9 + 11
@@ -109,8 +110,8 @@ def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
     for c in range(C):
         e, frac = elementwise_rel(P[c], ref[c])
         assert e < RTOL and frac > 0.2, (c, e, frac)  # (the tone's skirt leaves ~1/4 of the bins above the floor)
-        mref = ref[c] @ fb.T
-        assert (np.abs(mel[c] - mref) / mref).max() < RTOL
+        e, frac = elementwise_rel(mel[c], ref[c] @ fb.T)
+        assert e < RTOL and frac > 0.2, ("mel", c, e, frac)
 
 
 @pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 5), (256, 64, 2), (512, 128, 3), (4096, 1024, 2)])

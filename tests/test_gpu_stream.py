@@ -150,3 +150,42 @@ def test_hop_session_argument_errors():
     with pytest.raises(OnsetFPError):
         realtime.HopSession(2, 64, sr=48000, n_fft=300)
     sess.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hipass_freq=0, on_threshold=6.0, off_threshold=4.0),
+                                dict(backtrack=True, backtrack_buffer_size=512), "realtime"])
+def test_phase_split_block_kernel_equals_the_one_lane_per_channel_kernel(kw, monkeypatch):
+    """k_stream_par (phases staged in LDS, recurrences on separate lanes) against k_stream (one lane per
+    channel walks everything): same bytes for rel, same records, same carried state -- several blocks per
+    call, odd channel counts, with and without the high-pass, manual thresholds, backtracking."""
+    from onset_fingerprinting_amd import detection, realtime
+    if kw == "realtime":
+        kw = dict(realtime.REALTIME_DETECTOR_KWARGS)
+    C, B, sr = 5, 96, 48000
+    x = synth.drum_hits(C, 1.5, sr, seed=21, period=0.11)
+    nb = len(x) // B
+    xd = torch.from_numpy(x[: nb * B]).cuda()
+    outs = []
+    for mode in ("seq", "par"):
+        monkeypatch.setenv("OFP_STREAM_KERNEL", mode)
+        od = detection.AmplitudeOnsetDetector(C, B, sr=sr, **kw)
+        od.init_minmax_tracker(x[: 4000])
+        rel = torch.empty((nb * B, C), dtype=torch.float32, device="cuda")
+        rec = torch.zeros((4096, 16), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        k = 0
+        for n in (1, 7, 2, nb - 10):  # several calls of several blocks each: state hand-over both ways
+            od.process(xd[k * B:(k + n) * B], n, k * B, rel[k * B:(k + n) * B], rec, cnt)
+            k += n
+        torch.cuda.synchronize()
+        outs.append((rel.cpu().numpy().copy(), rec.cpu().numpy().copy(), int(cnt.item()), od._state.cpu().numpy().copy()))
+    assert outs[0][2] == outs[1][2] and outs[0][2] > 10
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    n_state = outs[0][3].size - B * C * 4  # (the trailing scratch block of the state is not state)
+    assert np.array_equal(outs[0][3][:n_state], outs[1][3][:n_state])
+    # and the oracle agrees
+    odet = oracle.OracleDetector(C, B, sr=sr, **kw)
+    odet.init_minmax_tracker(x[: 4000])
+    exp = np.concatenate([odet(np.ascontiguousarray(x[i * B:(i + 1) * B]))[2] for i in range(nb - 0)][: k])
+    assert np.array_equal(bits(outs[1][0][: k * B]), bits(exp))
