@@ -13,10 +13,16 @@
 //       rFFT, |X|^2, mel bands, the whole FCNN -- nothing but mel + logits leaves the chip)
 //   ->  D2H of one packed result block {count, records, logits, mel, rel}.
 //
+// Fused form (default whenever the detector fits one workgroup): the five nodes above collapse into ONE
+// kernel node, k_hop_fused -- workgroup 0 runs the detector while workgroups 1..C run the spectral
+// branch, the hop is read from and the result block written to pinned host memory directly.
+//
 // A replay needs no argument update: the write cursor is a counter in device memory.  The frame the
 // spectral kernel computes for the hop that ends at sample e is bit-identical to frame (e - n_fft)/B
 // of the dense kernel (k_stft_power, hop = B) on the same stream: same tables, same FFT, same mel
 // and classifier epilogue.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -24,6 +30,7 @@
 #include "ofp_detector.h"
 #include "ofp_fft.h"
 #include "ofp_mlp.h"
+#include "ofp_stream_dev.h"
 
 using namespace ofpfft;
 
@@ -68,10 +75,13 @@ struct HopCfg {
     static constexpr int WGS = T < 64 ? 64 : T;
 };
 
-template <int F>
-__global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
-    constexpr int M = HopCfg<F>::M, T = HopCfg<F>::T, WGS = HopCfg<F>::WGS;
-    extern __shared__ __align__(16) unsigned char smem[];
+// One channel's share of a hop: ring write, Hann x trailing n_fft samples, rFFT, |X|^2, mel bands and the
+// classifier.  Executed by one workgroup of WGS lanes (WGS == T when a frame needs more than one wave:
+// the FFT passes then synchronise with workgroup barriers); h = hops pushed including this one.
+template <int F, int WGS>
+__device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64_t h, unsigned char* smem) {
+    constexpr int M = HopCfg<F>::M, T = HopCfg<F>::T;
+    static_assert(T <= 64 ? WGS >= 64 : WGS == T, "lanes of a multi-wave frame must be the whole workgroup");
     float2* twM = reinterpret_cast<float2*>(smem);
     float2* twF = twM + M;
     float* win = reinterpret_cast<float*>(twF + M + 2);
@@ -83,8 +93,11 @@ __global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
     float* mprm = reinterpret_cast<float*>(foff + a.n_mels);
     float* tileA = mprm + ((a.plan.n_params + 3) & ~3);
     float* tileB = tileA + 16 * a.plan.st_a;
-    const int c = blockIdx.x, C = a.C, B = a.B;
+    float* hcol = tileB + 16 * a.plan.st_b;  // [B] this channel's column of the hop
+    const int C = a.C, B = a.B;
     const int tid = threadIdx.x;
+    // the hop may live in pinned host memory: every sample is fetched exactly once
+    for (int t = tid; t < B; t += WGS) hcol[t] = a.hop[(int64_t)t * C + c];
     // tables, filterbank and classifier parameters: L2-resident copies -> LDS
     for (int k = tid; k < M; k += WGS) twM[k] = a.twM[k];
     for (int k = tid; k <= M; k += WGS) twF[k] = a.twF[k];
@@ -98,16 +111,16 @@ __global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
     for (int i = tid; i < a.plan.n_params; i += WGS) mprm[i] = a.plan.params[i];
     if (a.plan.n_layers > 0)
         for (int i = tid; i < 16 * a.plan.st_a; i += WGS) tileA[i] = 0.0f;
-    const int64_t h = a.ctl[0];      // hops pushed including this one
     const int64_t first = (h - 1) * B;  // stream index of this hop's first sample
+    __syncthreads();
     // ring-buffer write of this channel's column (realtime/audio.py:97)
-    for (int t = tid; t < B; t += WGS) a.ring[((first + t) % a.R) * C + c] = a.hop[(int64_t)t * C + c];
+    for (int t = tid; t < B; t += WGS) a.ring[((first + t) % a.R) * C + c] = hcol[t];
     // trailing n_fft samples of the stream (realtime/recording.py:276: audio[-n_fft:]); samples before
     // the stream started read as the zeros the ring was created with
     const int64_t base = h * B - F;
     auto sample = [&](int64_t s) -> float {
         if (s < 0) return 0.0f;
-        if (s >= first) return a.hop[(s - first) * C + c];
+        if (s >= first) return hcol[s - first];
         return a.ring[(s % a.R) * C + c];
     };
     for (int p = tid; p < M; p += WGS)
@@ -154,6 +167,43 @@ __global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
     }
 }
 
+template <int F>
+__global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_spectral(HopArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    hop_spectral_body<F, HopCfg<F>::WGS>(a, blockIdx.x, a.ctl[0], smem);
+}
+
+// The whole hop in ONE launch: workgroup 0 is the detector (the phase-split block step of
+// ofp_stream_dev.h), workgroups 1..C the spectral branch of one channel each -- the two do not depend
+// on each other, so the hop takes max(detector, spectral) instead of their sum plus three launch gaps.
+// The hop is read straight from the pinned host buffer and the result block written straight to pinned
+// host memory (no copy nodes).  The hop counter is advanced by the workgroup that finishes last.
+template <int F>
+struct FusedCfg {
+    static constexpr int WGS = HopCfg<F>::T <= 64 ? 256 : HopCfg<F>::T;
+};
+
+template <int F>
+__global__ __launch_bounds__(FusedCfg<F>::WGS) void k_hop_fused(HopArgs a, ofpstream::StreamArgs sa) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t done = a.ctl[0];  // hops completed before this one
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *a.hop_index = done;
+        ofpstream::stream_par_blocks(sa, reinterpret_cast<float*>(smem));
+    } else {
+        hop_spectral_body<F, FusedCfg<F>::WGS>(a, (int)blockIdx.x - 1, done + 1, smem);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(a.ctl + 1), 1ull);
+        if (t == gridDim.x - 1) {  // every workgroup has read ctl[0]
+            a.ctl[1] = 0;
+            a.ctl[0] = done + 1;
+        }
+    }
+}
+
 }  // namespace
 
 struct ofp_hop_session {
@@ -179,6 +229,9 @@ struct ofp_hop_session {
     // result block layout (bytes)
     int64_t o_count = 0, o_index = 8, o_rec = 16, o_logits = 0, o_mel = 0, o_rel = 0, res_bytes = 0;
     HopArgs args;
+    ofpstream::StreamArgs sargs;  // fused form: the detector workgroup's arguments
+    bool fused = false;
+    size_t lds_fused = 0;
     size_t lds = 0;
     int64_t pushed = 0;   // hops submitted
     bool in_flight = false;
@@ -201,6 +254,36 @@ int hop_spectral(ofp_hop_session* s) {
     hipLaunchKernelGGL(k_hop_spectral<F>, dim3((unsigned)s->C), dim3(HopCfg<F>::WGS), s->lds, s->stream, s->args);
     OFP_LAUNCH_CHECK("k_hop_spectral");
     return OFP_OK;
+}
+
+template <int F>
+int hop_fused(ofp_hop_session* s) {
+    if (s->lds_fused > 65536 - 20480)  // (the detector's static LDS comes on top)
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hop_fused<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_fused));
+    hipLaunchKernelGGL(k_hop_fused<F>, dim3((unsigned)s->C + 1), dim3(FusedCfg<F>::WGS), s->lds_fused, s->stream, s->args,
+                       s->sargs);
+    OFP_LAUNCH_CHECK("k_hop_fused");
+    return OFP_OK;
+}
+
+int fused_threads(int n_fft) {
+    switch (n_fft) {
+        case 2048: return FusedCfg<2048>::WGS;
+        case 4096: return FusedCfg<4096>::WGS;
+        default: return 256;
+    }
+}
+
+int dispatch_fused(ofp_hop_session* s) {
+    switch (s->n_fft) {
+        case 256: return hop_fused<256>(s);
+        case 512: return hop_fused<512>(s);
+        case 1024: return hop_fused<1024>(s);
+        case 2048: return hop_fused<2048>(s);
+        case 4096: return hop_fused<4096>(s);
+    }
+    return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", s->n_fft);
 }
 
 int dispatch_tables(ofp_hop_session* s) {
@@ -227,6 +310,7 @@ int dispatch_spectral(ofp_hop_session* s) {
 
 // the per-hop sequence, enqueued on the session's stream (captured once, then replayed)
 int enqueue_hop(ofp_hop_session* s) {
+    if (s->fused) return dispatch_fused(s);  // one kernel: no copy nodes, no begin kernel
     OFP_HIP(hipMemcpyAsync(s->d_hop, s->h_hop, (size_t)s->B * s->C * sizeof(float), hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_hop_begin, dim3(1), dim3(64), 0, s->stream, s->args);
     OFP_LAUNCH_CHECK("k_hop_begin");
@@ -248,6 +332,7 @@ int reset_state(ofp_hop_session* s) {
     OFP_HIP(hipMemsetAsync(s->d_ctl, 0, 2 * sizeof(int64_t), s->stream));
     OFP_HIP(hipMemsetAsync(s->d_res, 0, (size_t)s->res_bytes, s->stream));
     OFP_HIP(hipStreamSynchronize(s->stream));
+    std::memset(s->h_res, 0, (size_t)s->res_bytes);
     s->pushed = 0;
     s->in_flight = false;
     return OFP_OK;
@@ -310,7 +395,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     const int M = s->n_fft / 2;
     const int st_a = cfg->mlp ? plan.st_a : 0, st_b = cfg->mlp ? plan.st_b : 0;
     s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)M * 8 + (size_t)cfg->fb_nnz * 4 +
-             (size_t)3 * s->n_mels * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + 64;
+             (size_t)3 * s->n_mels * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + (size_t)B * 4 + 64;
     int rc = OFP_OK;
     auto fail = [&](int code) {
         ofp_hop_destroy(s);
@@ -340,8 +425,8 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     HOP_TRY(hipMalloc(&s->d_fb_i, (size_t)3 * s->n_mels * 4));
     HOP_TRY(hipMalloc(&s->d_fb_w, (size_t)cfg->fb_nnz * 4));
     HOP_TRY(hipMalloc(&s->d_res, (size_t)s->res_bytes));
-    HOP_TRY(hipHostMalloc((void**)&s->h_hop, (size_t)B * C * 4, hipHostMallocDefault));
-    HOP_TRY(hipHostMalloc((void**)&s->h_res, (size_t)s->res_bytes, hipHostMallocDefault));
+    HOP_TRY(hipHostMalloc((void**)&s->h_hop, (size_t)B * C * 4, hipHostMallocMapped));
+    HOP_TRY(hipHostMalloc((void**)&s->h_res, (size_t)s->res_bytes, hipHostMallocMapped));
     std::memset(s->h_res, 0, (size_t)s->res_bytes);
     std::memset(s->h_hop, 0, (size_t)B * C * 4);
     HOP_TRY(hipMemcpy(s->d_fb_i, cfg->fb_lo, (size_t)s->n_mels * 4, hipMemcpyHostToDevice));
@@ -375,6 +460,39 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     a.mel = reinterpret_cast<float*>(s->d_res + s->o_mel);
     a.count = reinterpret_cast<int64_t*>(s->d_res + s->o_count);
     a.hop_index = reinterpret_cast<int64_t*>(s->d_res + s->o_index);
+    // Fused form (one launch per hop, hop and result block in pinned host memory) whenever the detector
+    // fits one workgroup of the fused kernel; OFP_HOP_GRAPH=nodes keeps the five-node graph.
+    {
+        const char* mode = getenv("OFP_HOP_GRAPH");
+        const size_t par_lds = (size_t)3 * B * C * sizeof(float);
+        s->fused = !(mode && mode[0] == 'n') && 2 * C <= fused_threads(s->n_fft) && C <= ofpstream::PAR_MAX_C &&
+                   par_lds <= 96 * 1024;
+        s->lds_fused = std::max(s->lds, par_lds);
+        if (s->fused) {
+            float* dev_hop = nullptr;
+            unsigned char* dev_res = nullptr;
+            HOP_TRY(hipHostGetDevicePointer((void**)&dev_hop, s->h_hop, 0));
+            HOP_TRY(hipHostGetDevicePointer((void**)&dev_res, s->h_res, 0));
+            a.hop = dev_hop;
+            a.logits = reinterpret_cast<float*>(dev_res + s->o_logits);
+            a.mel = reinterpret_cast<float*>(dev_res + s->o_mel);
+            a.count = reinterpret_cast<int64_t*>(dev_res + s->o_count);
+            a.hop_index = reinterpret_cast<int64_t*>(dev_res + s->o_index);
+            ofpstream::StreamArgs& q = s->sargs;
+            q = ofpstream::make_stream_args(det);
+            q.state = s->d_state;
+            q.x = dev_hop;
+            q.n_blocks = 1;
+            q.n_rows = 0;
+            q.warmup = 0;
+            q.sample_base = 0;
+            q.rel = s->want_rel ? reinterpret_cast<float*>(dev_res + s->o_rel) : nullptr;
+            q.records = reinterpret_cast<ofp_onset*>(dev_res + s->o_rec);
+            q.cap = C;
+            q.count = a.count;
+            q.fresh_count = 1;
+        }
+    }
     if ((rc = dispatch_tables(s)) != OFP_OK) return fail(rc);
     // one un-captured pass over zeros loads every code object and sets the kernel attributes
     // (neither may happen during capture), then the state is reset and the sequence captured

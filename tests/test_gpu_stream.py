@@ -78,8 +78,13 @@ def check_spectral(got, mel_ref, log_ref):
     # with the detector arguments of realtime/audio.py:39-52
     dict(C=3, B=128, sr=96000, F=2048, seconds=2.1, kw="realtime"),
 ])
-def test_hop_session_matches_the_oracle_hop_by_hop(cfg):
+@pytest.mark.parametrize("graph", ["fused", "nodes"])
+def test_hop_session_matches_the_oracle_hop_by_hop(cfg, graph, monkeypatch):
+    """graph = "fused": the default, ONE kernel node per hop (detector workgroup + one spectral workgroup
+    per channel, hop and result block in pinned host memory); "nodes": the five-node graph (H2D, begin,
+    detector, spectral, D2H) that shapes too large for the fused kernel take."""
     from onset_fingerprinting_amd import realtime
+    monkeypatch.setenv("OFP_HOP_GRAPH", graph)
     from onset_fingerprinting_amd.data import MelBank, stft_power_mel_mlp_dense
     from onset_fingerprinting_amd.pipeline import seeded_fcnn
     C, B, sr, F = cfg["C"], cfg["B"], cfg["sr"], cfg["F"]

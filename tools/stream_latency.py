@@ -13,6 +13,7 @@ line; the onsets of the replay are checked against a second, untimed replay afte
 timing loop must not disturb the result)."""
 import argparse
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -58,8 +59,11 @@ assert onsets == onsets2 and onsets > 0, (onsets, onsets2)
 print(json.dumps({
     "config": f"{args.config}: {C} ch @ {SR} Hz, hop {B}, n_fft {F}, 40 mel, "
               f"{'FCNN(40-10-10-10-8)' if clf is not None else 'no classifier'}; one hipGraph per hop "
-              "(H2D hop + k_hop_begin + k_stream + k_hop_spectral + D2H result block), ring buffer "
-              f"{sess.ring_samples} rows on the device",
+              + ("(H2D hop + k_hop_begin + k_stream_par + k_hop_spectral + D2H result block)"
+                 if os.environ.get("OFP_HOP_GRAPH", "")[:1] == "n" else
+                 "(ONE kernel node, k_hop_fused: detector workgroup + one spectral workgroup per channel, hop and "
+                 "result block in pinned host memory)") +
+              f", ring buffer {sess.ring_samples} rows on the device",
     "detector_kwargs": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()} or "reference defaults",
     "hops": hops, "p50_us": float(np.percentile(lat, 50) * 1e6), "p90_us": float(np.percentile(lat, 90) * 1e6),
     "p99_us": float(np.percentile(lat, 99) * 1e6), "max_us": float(lat.max() * 1e6), "mean_us": float(lat.mean() * 1e6),
