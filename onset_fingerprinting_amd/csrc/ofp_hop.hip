@@ -52,6 +52,8 @@ struct HopArgs {
     float* mel;            // [C][n_mels]
     int64_t* count;        // onset count of the hop (zeroed by k_hop_begin)
     int64_t* hop_index;    // result header: index of the hop this block belongs to
+    volatile int64_t* done_flag;  // fused form: hops completed, written to pinned host memory by the workgroup that
+                                  // finishes last, after every result of the hop (the host polls it)
 };
 
 __global__ void k_hop_begin(HopArgs a) {
@@ -195,11 +197,13 @@ __global__ __launch_bounds__(FusedCfg<F>::WGS) void k_hop_fused(HopArgs a, ofpst
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        __threadfence_system();  // this workgroup's results (host memory) before its ticket
         const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(a.ctl + 1), 1ull);
-        if (t == gridDim.x - 1) {  // every workgroup has read ctl[0]
+        if (t == gridDim.x - 1) {  // every workgroup has read ctl[0] and published its results
             a.ctl[1] = 0;
             a.ctl[0] = done + 1;
+            __threadfence_system();
+            *a.done_flag = done + 1;
         }
     }
 }
@@ -227,7 +231,7 @@ struct ofp_hop_session {
     float* h_hop = nullptr;           // pinned
     unsigned char* h_res = nullptr;   // pinned
     // result block layout (bytes)
-    int64_t o_count = 0, o_index = 8, o_rec = 16, o_logits = 0, o_mel = 0, o_rel = 0, res_bytes = 0;
+    int64_t o_count = 0, o_index = 8, o_done = 16, o_rec = 24, o_logits = 0, o_mel = 0, o_rel = 0, res_bytes = 0;
     HopArgs args;
     ofpstream::StreamArgs sargs;  // fused form: the detector workgroup's arguments
     bool fused = false;
@@ -478,6 +482,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
             a.mel = reinterpret_cast<float*>(dev_res + s->o_mel);
             a.count = reinterpret_cast<int64_t*>(dev_res + s->o_count);
             a.hop_index = reinterpret_cast<int64_t*>(dev_res + s->o_index);
+            a.done_flag = reinterpret_cast<volatile int64_t*>(dev_res + s->o_done);
             ofpstream::StreamArgs& q = s->sargs;
             q = ofpstream::make_stream_args(det);
             q.state = s->d_state;
@@ -545,7 +550,16 @@ int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records,
                     float* h_rel) {
     OFP_REQUIRE(s, "ofp_hop_collect: NULL session");
     OFP_REQUIRE(s->in_flight, "ofp_hop_collect: no hop in flight");
-    OFP_HIP(hipStreamSynchronize(s->stream));
+    if (s->fused) {
+        // the last workgroup publishes the hop count after every result: poll it instead of paying the
+        // stream synchronisation's wake-up (bounded: an error or a lost launch falls through to the sync)
+        const volatile int64_t* flag = reinterpret_cast<const volatile int64_t*>(s->h_res + s->o_done);
+        for (int spin = 0; spin < 2000000 && *flag != s->pushed; ++spin) __builtin_ia32_pause();
+        if (*flag != s->pushed) OFP_HIP(hipStreamSynchronize(s->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        OFP_HIP(hipStreamSynchronize(s->stream));
+    }
     s->in_flight = false;
     const unsigned char* r = s->h_res;
     int64_t count, index;

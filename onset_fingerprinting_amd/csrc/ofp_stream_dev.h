@@ -88,6 +88,33 @@ struct StreamArgs {
 // one-off warm-up take k_stream.
 constexpr int PAR_MAX_C = 512;
 
+// ofp_df2t4_step with the same operations in the same order, arranged as 2-wide vectors so that the
+// compiler can use packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are per-lane IEEE fp32): pairs (z0,z2) and
+// (z1,z3); the last tap adds -0.0f, exact for every addend.  10 instructions per sample instead of 17
+// (the same form the offline kernels use, csrc/ofp_detect.hip HpStep).
+typedef float ofp_v2f __attribute__((ext_vector_type(2)));
+struct HpPacked {
+    float z[4];
+    float b0;
+    ofp_v2f B13, B24, A13, A24;
+    __device__ void init(const float* b, const float* a, const float* z0) {
+        b0 = b[0];
+        B13 = ofp_v2f{b[1], b[3]}; B24 = ofp_v2f{b[2], b[4]};
+        A13 = ofp_v2f{a[1], a[3]}; A24 = ofp_v2f{a[2], a[4]};
+        for (int k = 0; k < 4; ++k) z[k] = z0[k];
+    }
+    __device__ float operator()(float xv) {
+        const ofp_v2f O = {z[1], z[3]};
+        const ofp_v2f Wz = {z[2], -0.0f};
+        const float y = z[0] + b0 * xv;
+        const ofp_v2f xx = {xv, xv}, yy = {y, y};
+        const ofp_v2f E2 = (O + B13 * xx) - A13 * yy;   // (z0', z2')
+        const ofp_v2f O2 = (Wz + B24 * xx) - A24 * yy;  // (z1', z3')
+        z[0] = E2.x; z[2] = E2.y; z[1] = O2.x; z[3] = O2.y;
+        return y;
+    }
+};
+
 template <class F>
 __device__ __forceinline__ void seq_walk(const float* __restrict__ in, int B, int C, F&& f) {
     // a lane's column of the staged block, eight loads ahead of the recurrence that consumes them
@@ -151,7 +178,12 @@ __device__ __forceinline__ void stream_par_blocks(const StreamArgs& a, float* sb
         const float* xb = p1;
         // 1: high-pass (:743-744)
         if (a.hp_on) {
-            if (act) seq_walk(xb + c, B, C, [&](int t, float v) { p0[t * C + c] = ofp_df2t4_step(v, a.b, a.a, z); });
+            if (act) {
+                HpPacked hp;
+                hp.init(a.b, a.a, z);
+                seq_walk(xb + c, B, C, [&](int t, float v) { p0[t * C + c] = hp(v); });
+                for (int k = 0; k < 4; ++k) z[k] = hp.z[k];
+            }
             __syncthreads();
         }
         // 2: rectified dB with floor (:747-748)

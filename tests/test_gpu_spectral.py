@@ -80,9 +80,11 @@ def test_dense_power_matches_oracle(data, n_fft, hop, C):
             assert err < RTOL, (clip, c, err)
 
 
-def elementwise_rel(got, ref, floor_frac=1e-6):
-    """max |got - ref| / |ref| over the elements with |ref| >= floor_frac * max|ref| (the floor below
-    which an fp32 FFT's absolute error, ~1e-7 of the largest bin, exceeds the bin itself)."""
+def elementwise_rel(got, ref, floor_frac=1e-5):
+    """max |got - ref| / |ref| over the elements with |ref| >= floor_frac * max|ref|.  Why a floor: an
+    fp32 FFT leaves an ABSOLUTE error of ~eps * |X|max on every bin, i.e. a relative error of
+    ~2 eps / sqrt(P / Pmax) on a power bin -- 4e-5 at P = 1e-5 Pmax (measured: 1.1e-4 at 1e-6 Pmax),
+    so 1e-4 relative is a meaningful bar for bins within 50 dB of the frame's largest and not below."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     big = np.abs(ref) >= floor_frac * np.abs(ref).max()
     return float((np.abs(got - ref)[big] / np.abs(ref)[big]).max()), float(big.mean())
@@ -91,10 +93,9 @@ def elementwise_rel(got, ref, floor_frac=1e-6):
 @pytest.mark.parametrize("n_fft,hop,C", [(1024, 256, 8), (2048, 512, 3), (256, 64, 2), (512, 128, 1), (4096, 1024, 2)])
 def test_dense_power_and_mel_elementwise(data, n_fft, hop, C):
     """north_star: "1e-4 relative fp32" -- ELEMENT-wise, not only norm-wise: every power bin that is at
-    least 1e-6 of the largest bin of its channel (an fp32 FFT's error floor is ~1e-7 of the largest
-    bin, so smaller bins carry no relative accuracy in an fp32 transform) and every mel band that is at
-    least 1e-6 of the largest band (sums of non-negative terms: no cancellation beyond the bins' own
-    error floor) within 1e-4 of the fp64 oracle."""
+    least 1e-5 of the largest bin of its channel (see elementwise_rel for the floor) and every mel band
+    that is at least 1e-5 of the largest band (sums of non-negative terms: no cancellation beyond the
+    bins' own error floor) within 1e-4 of the fp64 oracle."""
     from onset_fingerprinting_amd.data import MelBank, stft_power_mel_dense
     rng = np.random.default_rng(n_fft + 1)
     N = n_fft * 9 + 11
