@@ -1,182 +1,353 @@
 #!/usr/bin/env python3
 """Benchmark of the onset-fingerprinting hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4] [--clips n] [--inflight D]
 
-One step = one pass of detect -> rFFT |X|^2 -> 40-mel -> FCNN over one batch of
-synthetic audio already resident in HBM, plus (N > 1) the RCCL all-gather that
-collates onset records.  The detector is a chain of latency-bound recurrences that
-fills a fraction of the chip, so `--inflight` steps (default 8) are in flight at a
-time on each GPU, each on its own pipeline instance (work space, buffers, streams,
-host thread); every step is still one complete pass over one clip, steps complete and
-are gathered in order, and `config.latency_ms_per_step` reports what one step takes
-(`--inflight 1`: strictly one after the other).  In flight, the detector uses its throughput
-setting (`hp_span = 2`, `mm_chunk = 8192`, reported as `config.detector_tuning`; results are
-identical for every tuning).  Workload at every N: BASELINE.json configs[1] ("C2":
-8 ch x 60 s @ 48 kHz, 1024-point frames, hop 256) per GPU -- each rank owns an
-independent 8-channel clip (channels of one detector are coupled and a stream does
-not shard in time), so scaling is weak.  Rank 0 prints ONE JSON line.
+One step = one pass of detect -> rFFT |X|^2 -> 40-mel -> FCNN (the last three in ONE kernel) over one
+batch of synthetic clips already resident in HBM, followed by the exchange that collates the onset
+records (an RCCL all-gather when N > 1).  Rank 0 prints ONE JSON line.
+
+Launch.  `--gpus N` with N > 1 and no RANK in the environment makes THIS process a launcher: before
+anything touches a GPU it starts N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one
+process per GPU), waits for them, relays rank 0's JSON line and exits non-zero if any rank failed.
+Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are already there;
+`--gpus` must then equal WORLD_SIZE (anything else is refused, loudly).
+
+Workloads (BASELINE.json configs):
+  c2  (default at N = 1)  `--clips` (default 8) DISTINCT 8-channel 60 s clips per GPU and step
+      (configs[1], the configuration the metric is quoted on, as a batch: one library call processes
+      the clips side by side -- 64 chains).  Every rank owns its own clips: scaling "weak".
+      `config.one_clip_per_step` is the same path on ONE clip per step (8 chains, latency-bound).
+  c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
+      (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
+      the timed region) is the same 512 clips on one GPU -- the base the strong-scaling ratio refers to.
+`--inflight D` keeps D steps in flight per GPU, each on its own pipeline instance, clips, streams and
+host thread (default 1: steps strictly one after the other inside the barrier-bracketed window).
+
+`--rehearsal` (no GPU needed): the launcher, rendezvous, sharding, exchange, max-over-ranks timing and
+JSON line with fabricated onset records instead of GPU work -- the control flow of the N > 1 path for
+CPU tests (gloo).  Its `value` is not a measurement and says so.
 """
 import argparse
 import json
 import os
-
-# Steps in flight live on separate HIP streams; by default the runtime multiplexes all streams of a
-# process onto 4 hardware queues, which serialises unrelated steps behind each other's 2 ms kernels.
-# Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# Steps in flight live on separate HIP streams; by default the runtime multiplexes all streams of a
+# process onto 4 hardware queues.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-from onset_fingerprinting_amd import synth  # noqa: E402
-from onset_fingerprinting_amd.distributed import (all_gather_blocks, pack_block,  # noqa: E402
-                                                  records_to_numpy, unpack_gathered)
-from onset_fingerprinting_amd.pipeline import FingerprintPipeline  # noqa: E402
-
-SR, C, SECONDS, NFFT, HOP, NMELS = 48000, 8, 60.0, 1024, 256, 40
-GATHER_CAP = 4096  # onset records per rank and step in the all-gather block (C2 has 952)
+SR, NFFT, HOP, NMELS, NOUT = 48000, 1024, 256, 40, 8
+C2 = dict(C=8, seconds=60.0)
+C4 = dict(C=4, seconds=10.0, clips=512)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_NOFMA_PEAK_TFLOPS = 157.3 / 2  # the guide's fp32 vector peak counts an FMA as two operations
-# algorithmic bytes per frame: every input sample read once, every
-# required output written once
-BYTES_DETECT = 2 * 4 * HOP                 # 4 B read + 4 B rel write per sample
-BYTES_STFT = 4 * HOP + 4 * (NFFT // 2 + 1)  # new samples in, |X|^2 out
-BYTES_MEL = 4 * (NFFT // 2 + 1) + 4 * NMELS
-BYTES_MLP = 4 * NMELS + 4 * 8
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters (FETCH_SIZE doubled +
-# WRITE_SIZE, /opt/skills/guides/MI355X_MICROARCH.md section HBM); filled from profiles/, else null
-TRAFFIC_BYTES_PER_LAUNCH = {}
-try:  # measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes), see profiles/README.md
-    _t = json.load(open(REPO / "profiles" / "r01" / "v14_pmc_traffic_per_kernel.json"))
-    TRAFFIC_BYTES_PER_LAUNCH = {"hp": _t["k_hp_candidates"]["hbm_mb_per_launch"] * 1e6,
-                                "stft_mel": _t["k_stft_power"]["hbm_mb_per_launch"] * 1e6}
-except Exception:
-    pass
+# algorithmic bytes per frame: every input sample read once, every required output written once
+BYTES_DETECT = 2 * 4 * HOP                  # 4 B read + 4 B rel write per sample
+BYTES_SPECTRUM = 4 * (NFFT // 2 + 1)        # |X|^2 out (the samples are the detector's: read once)
+BYTES_FINGERPRINT = 4 * NMELS + 4 * NOUT    # mel + logits out
+BYTES_E2E = BYTES_DETECT + BYTES_SPECTRUM + BYTES_FINGERPRINT  # 4 100 + 192
+# PMC traffic per launch of the dominant kernels (FETCH_SIZE / WRITE_SIZE passes, corrected as the guide's
+# HBM section prescribes) is measured by tools/profile_round.sh, not in this run: the line names its source
+TRAFFIC_FILE = REPO / "profiles" / "r02" / "pmc_traffic_per_kernel.json"
 
 
-def cpu_baseline(x, seconds):
-    """The CPU oracle (a port, 1 thread) on the first `seconds` of the same clip."""
-    import oracle
-    n = int(seconds * SR)
-    xs = np.ascontiguousarray(x[:n])
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """The launcher: N children, one per GPU; relays rank 0's JSON line; non-zero exit if any rank fails
+    (the remaining ranks are then stopped -- they would wait for the lost one at the next barrier)."""
+    import tempfile
+    port = free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        deadline = time.time() + float(os.environ.get("OFP_BENCH_LAUNCH_TIMEOUT", "1500"))
+        failed = []
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed or all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                failed = [(r, "timeout") for r, c in enumerate(codes) if c is None]
+                break
+            time.sleep(0.05)
+        for p in procs:  # exactly the children started above
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        out0.seek(0)
+        lines = out0.read().decode(errors="replace").splitlines()
+    relayed = False
+    for line in lines:
+        if line.startswith("{") and not failed:
+            print(line)
+            relayed = True
+        elif line.strip():
+            sys.stderr.write(line + "\n")  # library chatter of rank 0 is not part of the contract's ONE line
+    sys.stdout.flush()
+    if failed or not relayed:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {failed}\n")
+        return 1
+    return 0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def fcnn_state():
     from onset_fingerprinting_amd.pipeline import seeded_fcnn
-    sd = {k: v.numpy() for k, v in seeded_fcnn(NMELS, 8).state_dict().items()}
+    return {k: v.numpy() for k, v in seeded_fcnn(NMELS, NOUT).state_dict().items()}
+
+
+def oracle_pass(x, sd):
+    """The CPU oracle (a port, 1 thread) on one clip: detect + dense |X|^2 + mel + FCNN."""
+    import numpy as np
+
+    import oracle
     fb = oracle.mel_filterbank(SR, NFFT, NMELS).astype(np.float64)
     t0 = time.perf_counter()
-    ch, on, rel = oracle.detect_onsets_amplitude(xs, block_size=HOP, sr=SR)
-    P = oracle.dense_power_frames(xs, NFFT, HOP)          # [C, H, bins]
+    ch, on, rel = oracle.detect_onsets_amplitude(x, block_size=HOP, sr=SR)
+    P = oracle.dense_power_frames(x, NFFT, HOP)          # [C, H, bins]
     mel = P @ fb.T
     logits = oracle.fcnn_forward(sd, mel.reshape(-1, NMELS))
     dt = time.perf_counter() - t0
-    frames = C * synth.n_frames(n, NFFT, HOP)
-    return dict(value=frames / dt, seconds=dt, frames=frames, ch=np.array(ch), on=np.array(on), rel=rel,
-                mel=mel, logits=logits.reshape(C, -1, 8))
+    return dict(seconds=dt, frames=x.shape[1] * P.shape[1], ch=np.array(ch), on=np.array(on), rel=rel, mel=mel,
+                logits=logits.reshape(x.shape[1], -1, NOUT))
+
+
+def _fanout_worker(job):
+    kind, seed, seconds, sd = job
+    from onset_fingerprinting_amd import synth
+    x = synth.c2_drums(seconds, C2["C"], SR, seed=seed) if kind == "c2" else synth.c4_clip(seed, seconds, C4["C"], SR)
+    r = oracle_pass(x, sd)
+    return r["frames"], r["seconds"]
+
+
+def _synth_worker(job):
+    kind, ident, seconds, C = job
+    from onset_fingerprinting_amd import synth
+    return synth.c2_drums(seconds, C, SR, seed=ident) if kind == "c2" else synth.c4_clip(ident, seconds, C, SR)
+
+
+def synth_batch(kind, idents, seconds, C, workers):
+    """The clips of one batch (host synthesis, several processes: a C2 clip takes seconds of numpy)."""
+    jobs = [(kind, int(i), seconds, C) for i in idents]
+    if workers <= 1 or len(jobs) == 1:
+        return [_synth_worker(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_synth_worker, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+
+
+def cpu_fanout(kind, seconds, sd):
+    """os.cpu_count() processes, one clip each (the process-per-core fan-out over clips)."""
+    import multiprocessing as mp
+    n = os.cpu_count() or 1
+    jobs = [(kind, 1000 + i, seconds, sd) for i in range(n)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(n) as pool:
+        res = pool.map(_fanout_worker, jobs)
+    wall = time.perf_counter() - t0
+    busy = max(s for _, s in res)  # the clips run side by side: the slowest one bounds the compute time
+    return dict(value=sum(f for f, _ in res) / busy, cores=n, wall_s=round(wall, 2),
+                sample=f"{n} processes x one {seconds:.0f} s clip each through oracle/, {busy:.2f} s for the slowest "
+                       "(process start-up and clip synthesis excluded)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds given to the CPU baseline")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["c2", "c4"], default=None)
+    ap.add_argument("--clips", type=int, default=8, help="c2: distinct clips per GPU and step")
+    ap.add_argument("--inflight", type=int, default=1, help="steps in flight per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=8, help="steps (clips) processed concurrently per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra figures (one clip per step, whole batch)")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
+    ap.add_argument("--rehearsal", action="store_true", help="control flow only, no GPU work (CPU tests)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # nothing in this process has touched a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to print a line whose n_gpus "
+                         "is not what was asked for (launch with --nproc-per-node equal to --gpus, or let bench.py "
+                         "start the ranks itself)\n")
+        sys.exit(2)
+    if os.environ.get("OFP_BENCH_TEST_FAIL_RANK") == str(rank):  # test hook: a rank that dies at start-up
+        sys.exit(3)
+    workload = args.workload or ("c2" if world == 1 else "c4")
+    rehearsal = args.rehearsal or os.environ.get("OFP_BENCH_REHEARSAL") == "1"
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from onset_fingerprinting_amd import synth
+    from onset_fingerprinting_amd.distributed import (all_gather_blocks, pack_clips, records_to_numpy, shard_range,
+                                                      unpack_gathered)
+
+    backend = os.environ.get("OFP_BENCH_BACKEND", "gloo" if rehearsal else "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL ("nccl" on ROCm); OFP_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse the
-        # control flow (RCCL refuses two ranks on one device)
-        backend = os.environ.get("OFP_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
+        if backend == "nccl":  # RCCL on ROCm
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
+        else:  # gloo: the ranks may share one GPU (or none, in a rehearsal)
             dist.init_process_group(backend, rank=rank, world_size=world)
             local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    x = synth.c2_drums(SECONDS, C, SR, seed=1 + rank)
-    xd = torch.from_numpy(x).to(dev).unsqueeze(0).contiguous()
-    # The detector is a chain of latency-bound recurrences that fills a fraction of the chip, so
-    # `--inflight` steps are processed concurrently, each by its own pipeline instance (work space,
-    # output buffers, HIP streams) driven by its own host thread; a step is still one full pass
-    # over one clip, and steps complete (and are all-gathered) in order.
-    D = max(1, args.inflight)
-    pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local) for _ in range(D)]
-    streams = [torch.cuda.Stream(dev) for _ in range(D)]
-    # With several steps in flight the detector runs in its throughput setting: ofp_detect_tuning.hp_span = 2
-    # (one speculative IIR run serves two chunks: 2/3 of the work in half the waves, a slightly longer
-    # launch) and mm_chunk = 8192 (tracker chunks twice as long: half the waves and half the overlapping
-    # window reads, 0.1 ms more for a lone step); the one-step-at-a-time figure below uses a pipeline with
-    # the library defaults.
-    tuning = json.loads(args.tuning) if args.tuning else ({"hp_span": 2, "mm_chunk": 8192} if D > 1 else {})
-    if tuning:
-        for pp in pipes:
-            pp.detector.set_tuning(**tuning)
-    pipe = pipes[0]
-    frames_per_rank = C * pipe.n_frames(x.shape[0])
-
-    stage_acc = {}
-    lat_acc = []
-    gather_acc = []
-
-    def run_step(w, timed):
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", local)
+    if not rehearsal:
         torch.cuda.set_device(local)
-        t_in = time.perf_counter()
-        with torch.cuda.stream(streams[w]):
-            out = pipes[w].run(xd, timed=timed)
-            # this rank's onset records as the fixed block the exchange uses, in a tensor of its own
-            # (no host round trip; the pipeline's buffers are free for its next step on return)
-            flat = pack_block(out["records"], out["counts"], GATHER_CAP, clip_offset=rank)
-        streams[w].synchronize()
-        return out, flat, time.perf_counter() - t_in
 
-    def finish(out, flat, lat, timed):
-        # the exchange: ONE all-gather of fixed-size blocks (count + records), no host round trip
-        t_g = time.perf_counter()
-        gathered = all_gather_blocks(flat)
-        if timed:
-            gather_acc.append(time.perf_counter() - t_g)  # host time of the exchange call (asynchronous under RCCL)
-            st = dict(out["info"]["stage_ms"])
-            st.pop("total")
-            st.update(out["spectral_ms"])  # runs concurrently with the detector on a second stream
-            for k, v in st.items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
-            lat_acc.append(lat)
-        return out, out["power"], out["mel"], out["logits"].reshape(-1, 8), gathered
-
-    from concurrent.futures import ThreadPoolExecutor
-    workers = [ThreadPoolExecutor(1) for _ in range(D)]  # worker w runs steps w, w+D, ... in order
-
-    def run_steps(n, timed):
-        # D steps in flight: worker w runs steps w, w+D, ... one after the other
-        futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n)]
-        res = None
-        for f in futs:  # complete in step order
-            out, flat, lat = f.result()
-            res = finish(out, flat, lat, timed)
-        return res
+    # ---- the rank's share of the workload
+    if workload == "c2":
+        C, seconds = C2["C"], C2["seconds"]
+        n_local, clip_lo, total_clips = max(1, args.clips), rank * max(1, args.clips), world * max(1, args.clips)
+        scaling = "weak"
+    else:
+        C, seconds = C4["C"], C4["seconds"]
+        clip_lo, clip_hi = shard_range(C4["clips"], rank, world)
+        n_local, total_clips = clip_hi - clip_lo, C4["clips"]
+        scaling = "strong"
+    N = int(seconds * SR)
+    H = synth.n_frames(N, NFFT, HOP)
+    frames_local = n_local * C * H
+    frames_total = total_clips * C * H
+    cap_clip = 4096 if workload == "c2" else 1024      # onset records per clip (C2 has ~950, a C4 clip ~160)
+    # records per rank in the exchanged block: the SAME size on every rank (an all-gather of equal blocks),
+    # so it is sized for the largest shard
+    n_local_max = n_local if workload == "c2" else -(-C4["clips"] // world)
+    cap_block = n_local_max * (1024 if workload == "c2" else 256)
+    D = max(1, args.inflight)
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        if not rehearsal:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    run_steps(max(args.warmup, D), False)
+    def make_clips(slot):
+        """[n_local, N, C] on the device.  c2: one DISTINCT clip per (rank, slot, clip): seed 1 + rank + 97*slot
+        + 7919*clip.  c4: clip ids clip_lo.. from the recipe for slot 0; further slots (steps in flight) are
+        distinct derived batches (channels rotated, gain changed) -- the host-side synthesis of another 512
+        clips would take longer than the whole bench."""
+        workers = max(1, (os.cpu_count() or 1) // world)
+        if workload == "c2":
+            xs = synth_batch("c2", [1 + rank + 97 * slot + 7919 * i for i in range(n_local)], seconds, C, workers)
+        else:
+            xs = synth_batch("c4", [clip_lo + i for i in range(n_local)], seconds, C, workers)
+        x = torch.from_numpy(np.stack(xs)).to(dev)
+        return x.contiguous(), xs[0]
+
+    def derive(slot0, slot):
+        """c4, steps in flight: a distinct batch per slot derived on the device (channels rotated, gain changed)."""
+        return (torch.roll(slot0[0], slot, dims=2) * (1.0 - 0.07 * slot)).contiguous(), None
+
+    tuning = json.loads(args.tuning) if args.tuning else {}
+    result_extra = {}
+    if rehearsal:
+        # fabricated detector output: 3 onsets per clip of this rank's shard
+        def fake_step():
+            rec = np.zeros((n_local, 4), dtype=np.dtype([("clip", np.int32), ("channel", np.int32), ("sample", np.int64)]))
+            rec["clip"] = np.arange(n_local)[:, None]
+            rec["channel"] = np.arange(4)[None, :] % C
+            rec["sample"] = 1000 * (clip_lo + np.arange(n_local))[:, None] + np.arange(4)[None, :]
+            r8 = torch.from_numpy(rec.view(np.uint8).reshape(n_local, 4, 16).copy())
+            return pack_clips(r8, torch.full((n_local,), 3, dtype=torch.int64), cap_block, clip_offset=clip_lo)
+
+        def run_steps(n, timed):
+            g = None
+            for _ in range(n):
+                g = all_gather_blocks(fake_step())
+            return g
+    else:
+        from onset_fingerprinting_amd.pipeline import FingerprintPipeline
+        if workload == "c2":
+            slots = [make_clips(s) for s in range(D)]
+        else:
+            slot0 = make_clips(0)
+            slots = [slot0] + [derive(slot0, s) for s in range(1, D)]
+        pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip) for _ in range(D)]
+        if tuning:
+            for pp in pipes:
+                pp.detector.set_tuning(**tuning)
+        streams = [torch.cuda.Stream(dev) for _ in range(D)]
+        stage_acc, lat_acc, gather_acc = {}, [], []
+
+        def run_step(w, timed):
+            torch.cuda.set_device(local)
+            t_in = time.perf_counter()
+            with torch.cuda.stream(streams[w]):
+                out = pipes[w].run(slots[w][0], timed=timed)
+                # this rank's onset records as the fixed block the exchange uses (compacted on the device)
+                blk = pack_clips(out["records"], out["counts"], cap_block, clip_offset=clip_lo)
+            streams[w].synchronize()
+            return out, blk, time.perf_counter() - t_in
+
+        def finish(out, blk, lat, timed):
+            t_g = time.perf_counter()
+            gathered = all_gather_blocks(blk)  # ONE collective of fixed-size blocks, no host round trip
+            if timed:
+                gather_acc.append(time.perf_counter() - t_g)
+                st = dict(out["info"]["stage_ms"])
+                st.pop("total")
+                st.update(out["spectral_ms"])
+                for k, v in st.items():
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v
+                lat_acc.append(lat)
+            return out, gathered
+
+        if D == 1:
+            def run_steps(n, timed):
+                res = None
+                for _ in range(n):
+                    res = finish(*run_step(0, timed), timed)
+                return res
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            workers = [ThreadPoolExecutor(1) for _ in range(D)]  # worker w runs steps w, w+D, ... in order
+
+            def run_steps(n, timed):
+                futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n)]
+                res = None
+                for f in futs:  # complete (and exchange) in step order
+                    res = finish(*f.result(), timed)
+                return res
+
+    # ---- W warm-up steps, then EXACTLY K timed steps between barriers; max over ranks
+    run_steps(max(args.warmup, D if not rehearsal else 1), False)
     barrier()
     t0 = time.perf_counter()
     res = run_steps(args.steps, True)
@@ -187,106 +358,160 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * frames_per_rank / (ms_per_step / 1e3)
+    value = frames_total / (ms_per_step / 1e3)
 
-    # the same steps strictly one after the other (outside the timed region above), so that the
-    # line also says what a single step costs when nothing else is in flight
-    single_ms = ms_per_step
-    if D > 1:
-        n1 = max(1, min(args.steps, 10))
-        w1 = D  # a pipeline of its own (default tuning), not one that holds a timed result
-        pipes.append(FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local))
-        streams.append(torch.cuda.Stream(dev))
-        run_step(w1, False)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            _, flat1, _ = run_step(w1, False)
-            all_gather_blocks(flat1)
-        barrier()
-        t = torch.tensor([(time.perf_counter() - t1) / n1 * 1e3], dtype=torch.float64, device=dev)
+    if rehearsal:
+        gathered = unpack_gathered(res)
+        recs = records_to_numpy(gathered)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "frames/sec (1024-pt, hop 256, 48 kHz) detect+FFT+classify at 1/2/4/8 MI355X",
+                "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                "dtype": "f32", "data": "rehearsal: fabricated onset records, no GPU work (control flow only, not a measurement)",
+                "config": {"workload": workload, "clips_total": total_clips, "clips_per_rank": n_local,
+                           "ranks_in_exchange": int(res.shape[0]), "backend": backend,
+                           "onsets_gathered": int(len(recs)), "clips_seen": int(len(np.unique(recs["clip"])))}}))
         if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        single_ms = float(t.item())
+            dist.destroy_process_group()
+        return
+
+    # ---- untimed extras on the same process: what one clip per step costs (c2) / the whole batch on one GPU (c4)
+    extras = {}
+    if not args.no_extras:
+        if workload == "c2" and (n_local > 1 or D > 1):
+            p1 = FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip)
+            x1 = slots[0][0][:1].contiguous()
+            s1 = torch.cuda.Stream(dev)
+            with torch.cuda.stream(s1):
+                p1.run(x1)
+                s1.synchronize()
+                barrier()
+                n1 = 10
+                t1 = time.perf_counter()
+                for _ in range(n1):
+                    o1 = p1.run(x1)
+                    pack_clips(o1["records"], o1["counts"], 1024)
+                    s1.synchronize()
+                ms1 = (time.perf_counter() - t1) / n1 * 1e3
+            extras["one_clip_per_step"] = {"ms_per_step": round(ms1, 3), "frames_per_s": round(C * H / (ms1 / 1e3)),
+                                           "note": "the same path on ONE 8-channel clip per step (8 chains), steps one "
+                                                   "after the other, this rank only"}
+            del p1
+        if workload == "c4" and world > 1 and rank == 0:
+            pw = FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip)
+            xw = slots[0][0].repeat((total_clips + n_local - 1) // n_local, 1, 1)[:total_clips].contiguous()
+            # (rank 0's shard tiled to 512 clips: the same shapes and amount of work as the whole batch)
+            sw = torch.cuda.Stream(dev)
+            with torch.cuda.stream(sw):
+                pw.run(xw)
+                sw.synchronize()
+                nw = 3
+                tw = time.perf_counter()
+                for _ in range(nw):
+                    ow = pw.run(xw)
+                    pack_clips(ow["records"], ow["counts"], total_clips * 256)
+                    sw.synchronize()
+                msw = (time.perf_counter() - tw) / nw * 1e3
+            extras["whole_batch_on_one_gpu"] = {"ms_per_step": round(msw, 3), "frames_per_s": round(frames_total / (msw / 1e3)),
+                                                "strong_scaling_vs_it": round((msw / ms_per_step) / world, 3),
+                                                "note": "rank 0 alone on 512 clips (its shard tiled), after the timed region"}
+            del pw, xw
+        if world > 1:
+            dist.barrier()
 
     if rank == 0:
-        out, power, mel, logits, gathered = res
+        out, gathered = res
         gathered = unpack_gathered(gathered)  # decode (and check) the last step's exchange
+        recs = records_to_numpy(gathered)
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
-        stage_bytes = dict(hp=BYTES_DETECT, db=BYTES_DETECT, ar=BYTES_DETECT, rel=BYTES_DETECT, mm=BYTES_DETECT // 2,
-                           logic=BYTES_DETECT // 2, stft_mel=BYTES_STFT + 4 * NMELS, mlp=BYTES_MLP)
         cand_ms = stage_ms.pop("hp_candidates", 0.0)  # a part of the hp stage, reported separately
-        dom = max(stage_ms, key=stage_ms.get)
         passes = out["info"]
-        launches = 1
-        dom_ms = stage_ms[dom]
+        stage_bytes = dict(hp=BYTES_DETECT, db=BYTES_DETECT, ar=BYTES_DETECT, rel=BYTES_DETECT, mm=BYTES_DETECT // 2,
+                           logic=BYTES_DETECT // 2, stft_mel=4 * HOP + BYTES_SPECTRUM + BYTES_FINGERPRINT, mlp=0)
+        kernels = {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm2+k_ar_chunk",
+                   "mm": "k_mm_warm2+k_mm_chunk", "db": "k_rect_db", "rel": "k_rel_out",
+                   "logic": "k_block_scan+k_last_clear+k_visits+k_state_machine",
+                   "stft_mel": "k_stft_power<1024, mlp> (mel + FCNN in the epilogue)", "mlp": "-"}
+        dom = max((k for k in stage_ms if k in stage_bytes), key=lambda k: stage_ms[k])
+        dom_ms, dom_bytes = stage_ms[dom], stage_bytes[dom]
         if dom == "hp" and cand_ms > 0:
-            # the dominant KERNEL is the single k_hp_candidates launch of the IIR stage: it reads
-            # every input sample once (4 B) and keeps only chunk-boundary states
+            # the dominant KERNEL is the single k_hp_candidates launch of the IIR stage: it reads every input
+            # sample once (4 B) and keeps only chunk-boundary states
             dom_ms, dom_bytes = cand_ms, 4 * HOP
-        else:
-            dom_bytes = stage_bytes[dom]
-        achieved = dom_bytes * frames_per_rank / (dom_ms / 1e3) / 1e9
+        achieved = dom_bytes * frames_local / (dom_ms / 1e3) / 1e9
         stage_ms["hp_candidates(part of hp)"] = cand_ms
+        traffic, traffic_src = None, None
+        if TRAFFIC_FILE.exists():
+            tj = json.load(open(TRAFFIC_FILE))
+            key = {"hp": "k_hp_candidates", "stft_mel": "k_stft_power"}.get(dom)
+            if key in tj:
+                traffic = tj[key]["hbm_mb_per_launch"] * 1e6
+                traffic_src = f"{TRAFFIC_FILE.relative_to(REPO)} (separate rocprofv3 --pmc passes of this command, not this run)"
+        e2e_gbs = BYTES_E2E * frames_total / (ms_per_step / 1e3) / 1e9
+        if workload == "c2":
+            wl = (f"C2 x {n_local} per GPU and step: {n_local} distinct 8 ch x 60 s @ 48 kHz drum-hit clips side by side, "
+                  "1024/256, detect + rFFT |X|^2 + 40-mel + FCNN(40-10-10-10-8); exchange of the onset records")
+        else:
+            wl = (f"C4: 512 clips x 4 ch x 10 s @ 48 kHz (Poisson hits) sharded {n_local} clips per GPU, 1024/256, "
+                  "detect + rFFT |X|^2 + 40-mel + FCNN(40-10-10-10-8); RCCL all-gather of the onset records")
         result = {
             "metric": "frames/sec (1024-pt, hop 256, 48 kHz) detect+FFT+classify at 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 per GPU: 8 ch x 60 s @ 48 kHz drum hits, 1024/256, "
-                                   "detect + rFFT |X|^2 + 40-mel + FCNN(40-10-10-10-8); RCCL all-gather of onsets",
-                       "frames_per_gpu": frames_per_rank, "onsets_gathered": int(gathered.shape[0]),
-                       "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D, "detector_tuning": tuning,
-                       "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
-                       "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3),
-                       "one_step_at_a_time": {"ms_per_step": round(single_ms, 3),
-                                              "frames_per_s": round(world * frames_per_rank / (single_ms / 1e3))}},
-            "roofline": {"bound": "hbm", "kernel": {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm2+k_ar_chunk",
-                                                    "mm": "k_mm_warm2+k_mm_chunk", "db": "k_rect_db",
-                                                    "rel": "k_rel_out", "logic": "k_block_scan+k_state_machine",
-                                                    "stft_mel": "k_stft_power<1024> (mel fused)", "mlp": "k_dense"}[dom],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "launches_per_step": launches,
-                         "avg_launch_ms": dom_ms / launches,
-                         "algorithmic_bytes_per_frame": dom_bytes,
-                         "note": "latency-bound sequential recurrence (8 chains): see DESIGN.md section 5"},
+            "config": dict({"workload": wl, "clips_per_gpu_per_step": n_local, "clips_total_per_step": total_clips,
+                            "frames_per_step": frames_total, "frames_per_gpu_per_step": frames_local,
+                            "onsets_gathered": int(len(recs)), "ranks_in_exchange": world, "backend": backend if world > 1 else "-",
+                            "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D, "detector_tuning": tuning or "library defaults",
+                            "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
+                            "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3)}, **extras),
+            "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches_per_step": 1, "avg_launch_ms": dom_ms, "algorithmic_bytes_per_frame": dom_bytes,
+                         "note": "per launch: algorithmic bytes of the launch / its duration (HIP events on its stream)"},
+            "roofline_e2e": {"bound": "hbm", "achieved": e2e_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": e2e_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_frame": BYTES_E2E,
+                             "note": "whole step: 4 292 B per frame (samples in, rel + |X|^2 + mel + logits out) x frames / ms_per_step"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "detector_passes": {k: passes[k] for k in ("hp_passes", "ar_passes", "mm_passes", "repaired")},
         }
         if dom == "hp" and cand_ms > 0 and passes.get("hp_candidate_steps"):
-            # what actually bounds k_hp_candidates: the fp32 operations of its speculative IIR steps (17 each,
-            # no FMA: every operation is rounded as the reference rounds it) against the vector fp32 rate
-            # without FMA (157.3 TFLOP/s counts an FMA as 2)
             flop = 17.0 * passes["hp_candidate_steps"]
             tf = flop / (cand_ms / 1e3) / 1e12
-            result["roofline"]["issue"] = {"bound": "valu fp32 without fma", "flop_per_launch": flop,
-                                           "achieved": tf, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": tf / VALU_NOFMA_PEAK_TFLOPS,
-                                           # the launches of all steps in flight together: one launch per ms_per_step
-                                           "achieved_chip": flop / (ms_per_step / 1e3) / 1e12,
-                                           "frac_chip": flop / (ms_per_step / 1e3) / 1e12 / VALU_NOFMA_PEAK_TFLOPS}
+            result["roofline"]["issue"] = {"bound": "valu fp32 without fma", "flop_per_launch": flop, "achieved": tf,
+                                           "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_NOFMA_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(x, min(args.cpu_seconds, SECONDS))
-            # parity of the timed GPU result against the oracle on the same sample
-            n = int(min(args.cpu_seconds, SECONDS) * SR)
-            recs = records_to_numpy(gathered)
-            k = recs["sample"] < (n // HOP) * HOP
-            # onsets of the prefix are identical only up to the last block boundary effects: compare strictly
-            # on records whose block lies inside the sample
-            ok_idx = np.array_equal(recs["channel"][k], cb["ch"]) and np.array_equal(recs["sample"][k], cb["on"])
-            nb = (n // HOP) * HOP
-            ok_rel = np.array_equal(out["rel"][0, :nb].cpu().numpy().view(np.uint32), cb["rel"].view(np.uint32))
+            secs = min(args.cpu_seconds, seconds)
+            n = int(secs * SR)
+            sd = fcnn_state()
+            last = (args.steps - 1) % D
+            if slots[last][1] is None:  # c4 with steps in flight: only slot 0 has a host copy
+                last = 0
+                out, _ = finish(*run_step(0, False), False)
+                recs = records_to_numpy(unpack_gathered(_))
+            x0 = np.ascontiguousarray(slots[last][1][:n])   # clip 0 of the batch the checked step ran on
+            cb = oracle_pass(x0, sd)
+            r0 = recs[recs["clip"] == 0]
+            k = r0["sample"] < (n // HOP) * HOP
+            ok_idx = np.array_equal(r0["channel"][k], cb["ch"]) and np.array_equal(r0["sample"][k], cb["on"])
+            nbs = (n // HOP) * HOP
+            ok_rel = np.array_equal(out["rel"][0, :nbs].cpu().numpy().view(np.uint32), cb["rel"].view(np.uint32))
             Hs = cb["mel"].shape[1]
-            gm = mel[0, :, :Hs].cpu().numpy()
-            mel_err = float(np.abs(gm - cb["mel"]).max() / cb["mel"].max())
-            gl = logits.reshape(C, -1, 8)[:, :Hs].cpu().numpy()
+            gm = out["mel"][0, :, :Hs].cpu().numpy()
+            mel_err = float((np.abs(gm - cb["mel"]) / cb["mel"]).max())
+            gl = out["logits"][0, :, :Hs].cpu().numpy()
             log_err = float(np.abs(gl - cb["logits"]).max() / np.abs(cb["logits"]).max())
-            result["cpu_baseline"] = {"value": cb["value"], "unit": "frames/s", "cores": 1, "kind": "port",
-                                      "sample": f"the first {min(args.cpu_seconds, SECONDS):.0f} s of the same 60 s clip "
-                                                f"({cb['frames']} frames) through oracle/ (C detector + numpy "
-                                                f"rFFT/mel/FCNN), {cb['seconds']:.2f} s wall"}
+            fan = cpu_fanout(workload, secs, sd)
+            result["cpu_baseline"] = {"value": cb["frames"] / cb["seconds"], "unit": "frames/s", "cores": 1, "kind": "port",
+                                      "cpu_model": cpu_model(),
+                                      "sample": f"the first {secs:.0f} s of clip 0 of the timed batch ({cb['frames']} frames) "
+                                                f"through oracle/ (C detector + numpy rFFT/mel/FCNN), {cb['seconds']:.2f} s wall",
+                                      "fanout": {"value": fan["value"], "unit": "frames/s", "cores": fan["cores"],
+                                                 "sample": fan["sample"]}}
             result["parity"] = {"onset_indices_exact": bool(ok_idx), "rel_bit_exact": bool(ok_rel),
-                                "mel_max_rel_err": mel_err, "logits_max_rel_err": log_err}
+                                "mel_max_rel_err_elementwise": mel_err, "logits_max_rel_err": log_err,
+                                "checked": "clip 0 of the last timed step against the oracle"}
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -74,6 +74,35 @@ def pack_block(records, counts, cap, clip_offset=0):
     return block
 
 
+def pack_clips(records, counts, cap_total, clip_offset=0):
+    """Detector output of a batch of clips -> ONE fixed block for `all_gather_blocks`, compacted on the
+    device without a host round trip (no data-dependent shape): records [n_clips, cap, 16] uint8,
+    counts [n_clips] int64 -> [1 + cap_total, 16]; record 0 carries the total count (decoded and checked
+    against cap_total by `unpack_gathered`), records 1.. are the valid records of clip 0, clip 1, ... in
+    order with `clip_offset` added to their clip ids; rows beyond the count are don't-care."""
+    n_clips, cap = records.shape[0], records.shape[1]
+    dev = records.device
+    c = counts.to(torch.int64).clamp(max=cap)
+    offs = torch.cumsum(c, 0) - c                                   # first output row of each clip
+    k = torch.arange(cap, device=dev, dtype=torch.int64)[None, :]
+    pos = torch.where(k < c[:, None], 1 + offs[:, None] + k, torch.full_like(k, cap_total + 1))
+    pos = pos.clamp(max=cap_total + 1).reshape(-1)                  # overflow and padding rows -> the dump row
+    block = torch.zeros((cap_total + 2, 16), dtype=torch.uint8, device=dev)
+    src = records.reshape(n_clips * cap, 16)
+    if clip_offset:
+        src = src.clone()
+        clip = src[:, :4].contiguous().view(torch.int32)
+        clip += int(clip_offset)
+        src[:, :4] = clip.view(torch.uint8)
+    block.index_copy_(0, pos, src)
+    block[0] = 0
+    block[0, 8:16] = c.sum().reshape(1).view(torch.uint8)
+    # record 0's channel field flags a clip with more onsets than its record capacity (a lost record is an
+    # error, not a truncation: `unpack_gathered` raises)
+    block[0, 4:8] = (counts.to(torch.int64) > cap).any().to(torch.int32).reshape(1).view(torch.uint8)
+    return block[: cap_total + 1]
+
+
 def all_gather_blocks(block, group=None):
     """All-gather of one fixed block [1 + cap, 16] per rank (see `pack_block`) -> [world, 1 + cap, 16]:
     one collective, no host round trip."""
@@ -101,7 +130,10 @@ def all_gather_onsets_padded(local_records, cap, group=None):
 def unpack_gathered(blocks):
     """[world, 1 + cap, 16] from `all_gather_onsets_padded` -> concatenated records [total, 16]."""
     cap = blocks.shape[1] - 1
-    counts = blocks[:, 0, 8:16].contiguous().view(torch.int64).reshape(-1).cpu().tolist()
+    head = blocks[:, 0].cpu()
+    counts = head[:, 8:16].contiguous().view(torch.int64).reshape(-1).tolist()
+    if int(head[:, 4:8].contiguous().view(torch.int32).max()) != 0:
+        raise RuntimeError("a clip produced more onsets than its record capacity (cap_per_clip)")
     if max(counts, default=0) > cap:
         raise RuntimeError(f"{max(counts)} onset records on a rank exceed the gather capacity {cap}")
     return torch.cat([blocks[r, 1:1 + c] for r, c in enumerate(counts)], dim=0)

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .calibration import FCNN
-from .data import MelBank, stft_power_mel_dense
+from .data import MelBank, stft_power_mel_dense, stft_power_mel_mlp_dense
 from .detection import BatchDetector
 
 
@@ -39,13 +39,20 @@ def seeded_fcnn(n_in=40, n_out=8, seed=1234):
 
 class FingerprintPipeline:
     def __init__(self, n_channels, n_fft=1024, hop=256, sr=48000, n_mels=40, classifier=None, device=0,
-                 **detector_kwargs):
+                 want_power=True, cap_per_clip=None, **detector_kwargs):
         self.device = torch.device("cuda", int(device))
         _lib.require_gpu(int(device))
         self.n_channels, self.n_fft, self.hop, self.sr, self.n_mels = n_channels, n_fft, hop, sr, n_mels
         self.detector = BatchDetector(n_channels, block_size=hop, sr=sr, device=device, **detector_kwargs)
         self.mel = MelBank(sr, n_fft, n_mels, device=device)
         self.classifier = classifier if classifier is not None else seeded_fcnn(n_mels, 8)
+        # an FCNN runs inside the STFT kernel's epilogue (ofp_stft_power_mel_mlp); any other callable
+        # classifier gets the mel bands afterwards
+        self._mlp = self.classifier.device_mlp(self.device) if hasattr(self.classifier, "device_mlp") else None
+        if self._mlp is not None and not self._mlp.fits:
+            self._mlp = None
+        self.want_power = bool(want_power)  # False: |X|^2 never leaves the chip (BASELINE config 3)
+        self.cap_per_clip = cap_per_clip
         self._bufs = None
         self._side = None
 
@@ -58,13 +65,16 @@ class FingerprintPipeline:
             C, H, bins = self.n_channels, self.n_frames(N), self.n_fft // 2 + 1
             nb = N // self.hop
             dev = self.device
+            cap = int(self.cap_per_clip) if self.cap_per_clip else max(1, min(nb * C, 1 << 20))
+            n_out = self._mlp.n_out if self._mlp is not None else 0
             self._bufs = dict(
                 key=key,
-                det=dict(records=torch.empty((n_clips, max(1, min(nb * C, 1 << 20)), 16), dtype=torch.uint8, device=dev),
+                det=dict(records=torch.empty((n_clips, cap, 16), dtype=torch.uint8, device=dev),
                          counts=torch.zeros(n_clips, dtype=torch.int64, device=dev),
                          rel=torch.empty((n_clips, nb * self.hop, C), dtype=torch.float32, device=dev)),
-                power=torch.empty((n_clips, C, H, bins), dtype=torch.float32, device=dev),
+                power=torch.empty((n_clips, C, H, bins), dtype=torch.float32, device=dev) if self.want_power else None,
                 mel=torch.empty((n_clips, C, H, self.n_mels), dtype=torch.float32, device=dev),
+                logits=torch.empty((n_clips, C, H, n_out), dtype=torch.float32, device=dev) if n_out else None,
             )
             self.detector.reserve(n_clips, N, int(0.5 * self.sr))
         return self._bufs
@@ -93,14 +103,23 @@ class FingerprintPipeline:
         side.wait_event(self._head)
         with torch.cuda.stream(side):
             self._ev[0].record(side)
-            # |X|^2 and the mel bands of every frame in one kernel (the filterbank is applied while
-            # the frame's power spectrum is still in LDS)
-            # (it reads the transposed copy of x the detector's head just made: coalesced loads)
-            power, mel = stft_power_mel_dense(x, self.n_fft, self.hop, self.mel, out_power=b["power"],
-                                              out_mel=b["mel"], planar=self.detector.planar_input(x))
-            self._ev[1].record(side)
-            self._ev[2].record(side)
-            logits = self.classifier(mel.reshape(-1, self.n_mels))
+            # |X|^2, the mel bands and the classifier of every frame in ONE kernel: the filterbank is
+            # applied while the frame's power spectrum is still in LDS, the FCNN while the band sums
+            # of 16 frames are (it reads the transposed copy of x the detector's head just made:
+            # coalesced loads)
+            planar = self.detector.planar_input(x)
+            if self._mlp is not None:
+                power, mel, logits = stft_power_mel_mlp_dense(
+                    x, self.n_fft, self.hop, self.mel, self._mlp, out_power=b["power"], out_mel=b["mel"],
+                    out_logits=b["logits"], want_power=self.want_power, want_mel=True, planar=planar)
+                self._ev[1].record(side)
+                self._ev[2].record(side)
+            else:
+                power, mel = stft_power_mel_dense(x, self.n_fft, self.hop, self.mel, out_power=b["power"],
+                                                  out_mel=b["mel"], want_power=self.want_power, planar=planar)
+                self._ev[1].record(side)
+                self._ev[2].record(side)
+                logits = self.classifier(mel.reshape(-1, self.n_mels))
             self._ev[3].record(side)
         det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1], begun=True)
         main.wait_stream(side)

@@ -8,8 +8,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import pytest
+
 from onset_fingerprinting_amd.distributed import (ONSET_DTYPE, all_gather_blocks, all_gather_onsets,
-                                                  all_gather_onsets_padded, flatten_records, pack_block,
+                                                  all_gather_onsets_padded, flatten_records, pack_block, pack_clips,
                                                   records_to_numpy, shard_range, unpack_gathered)
 
 
@@ -103,3 +105,26 @@ def test_single_process_is_identity():
     want = flatten_records(one, torch.from_numpy(counts[2:3]), 8, clip_offset=4)
     assert torch.equal(unpack_gathered(all_gather_blocks(blk)), want)
 
+
+
+def test_pack_clips_compacts_without_data_dependent_shapes():
+    """The block bench.py exchanges for a batch of clips: same records, same order as flatten_records,
+    fixed shape; overflow of the block or of a clip's record capacity is an error at unpack time."""
+    rng = np.random.default_rng(0)
+    n_clips, cap = 5, 7
+    recs = np.zeros((n_clips, cap), ONSET_DTYPE)
+    recs["clip"] = np.arange(n_clips)[:, None]
+    recs["channel"] = rng.integers(0, 4, (n_clips, cap))
+    recs["sample"] = rng.integers(0, 1000, (n_clips, cap))
+    r8 = _as_u8(recs)
+    counts = torch.tensor([3, 0, 7, 2, 1])
+    blk = pack_clips(r8, counts, 32, clip_offset=10)
+    assert blk.shape == (33, 16)
+    assert torch.equal(unpack_gathered(all_gather_blocks(blk)), flatten_records(r8, counts, cap, clip_offset=10))
+    assert torch.equal(unpack_gathered(all_gather_blocks(pack_clips(r8, counts, 13))), flatten_records(r8, counts, cap))
+    with pytest.raises(RuntimeError):
+        unpack_gathered(all_gather_blocks(pack_clips(r8, counts, 12)))          # 13 records do not fit 12
+    with pytest.raises(RuntimeError):
+        unpack_gathered(all_gather_blocks(pack_clips(r8, torch.tensor([3, 0, 9, 2, 1]), 32)))  # clip 2 lost 2 records
+    empty = pack_clips(r8, torch.zeros(5, dtype=torch.int64), 4)
+    assert unpack_gathered(all_gather_blocks(empty)).shape == (0, 16)
