@@ -40,7 +40,7 @@ extern "C" {
 #define OFP_ERR_WORKSPACE 4 /* caller-provided work space too small */
 #define OFP_ERR_NOCONVERGE 5 /* speculative time-parallel pass did not converge */
 
-#define OFP_ABI_VERSION 1
+#define OFP_ABI_VERSION 2
 
 /* ---- status ---------------------------------------------------------------- */
 int ofp_abi_version(void);
@@ -118,6 +118,10 @@ typedef struct ofp_detect_tuning {
     int64_t hp_span;             /* IIR stage: 1 (default), 2 or 4 = chunks one speculative run walks through
                                     after its warm-up; > 1 shares the warm-up between chunks: less work,
                                     fewer waves, longer launch (throughput instead of latency) */
+    int64_t ar_span, mm_span;    /* follower / tracker stage: chunks one speculative warm-up run walks through
+                                    (0: chosen from the batch size, see make_layout) */
+    int64_t verify_group;        /* verification passes / rounds enqueued per host synchronisation (0: default 2-3;
+                                    1: one host round trip per pass, the round-1 behaviour) */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

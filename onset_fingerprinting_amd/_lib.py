@@ -54,6 +54,9 @@ class DetectTuning(ctypes.Structure):
         ("hp_candidate_offset", ctypes.c_int64),
         ("ar_guess", ctypes.c_int64),
         ("hp_span", ctypes.c_int64),
+        ("ar_span", ctypes.c_int64),
+        ("mm_span", ctypes.c_int64),
+        ("verify_group", ctypes.c_int64),
     ]
 
 

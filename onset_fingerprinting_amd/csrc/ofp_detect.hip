@@ -347,6 +347,7 @@ struct ArArgs {
     float* dif;        // planar
     float fa, fr, sa, sr, floor_db;
     int64_t L, W, Wc, Wf, n_chunks;
+    int64_t S;  // span of k_ar_warm2: chunks one speculative run walks through after its warm-up
 };
 
 // The stage is split into LEAN kernels, one walk instantiation each: measured on gfx950, the
@@ -478,27 +479,41 @@ __global__ __launch_bounds__(64) void k_ar_warm(ArArgs a, int64_t n_threads, uin
 // starts from the floor and forgets it within ~24 of its own time constants, walks the last Wf
 // samples only (second half), each with half the instructions per step.
 __global__ __launch_bounds__(64) void k_ar_warm2(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    // SPAN: one lane = one run that warms up before chunk k0 = g*S and then walks on through the S-1
+    // following chunks, leaving the state it passes every boundary with as that chunk's start guess (a
+    // guess with a LONGER warm-up than its own run would have had).  Per chunk the launch reads and
+    // steps (W + (S-1) L) / S samples instead of W: the overlapping windows of neighbouring chunks were
+    // most of this stage's memory traffic.  n_threads = chains * ceil(n_chunks / S).
     OFP_LATENCY_BOUND_KERNEL();
     const int64_t half = (n_threads + 63) / 64;
     const bool fast = blockIdx.x >= half;
     const int64_t id = ((int64_t)blockIdx.x - (fast ? half : 0)) * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
-    const int64_t k = id % a.n_chunks;
-    const int64_t chain = id / a.n_chunks;
-    const int64_t start = k * a.L;
-    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const int64_t n_groups = cdiv(a.n_chunks, a.S);
+    const int64_t g = id % n_groups;
+    const int64_t chain = id / n_groups;
+    const int64_t k0 = g * a.S;
+    const int64_t start = k0 * a.L;
     const float* xs = a.xdb + chain * a.g.U;
     int norem = -1;
     if (!fast) {
         const int64_t ws = max<int64_t>(start - a.W, 0);
-        ArOne s{ofp_u2f(used[sidx + 1]), a.sa, a.sr};
+        ArOne s{ofp_u2f(used[(chain * a.n_chunks + k0) * 2 + 1]), a.sa, a.sr};  // closed-form guess at the run's start
         walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
-        used[sidx + 1] = ofp_f2u(s.y);
+        used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(s.y);
+        for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+            walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
+            used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.y);
+        }
     } else {
         const int64_t ws = max<int64_t>(start - min(a.W, a.Wf), 0);
         ArOne s{a.floor_db, a.fa, a.fr};  // the true state at sample 0 (:697-702), a guess elsewhere
         walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
-        used[sidx] = ofp_f2u(s.y);
+        used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(s.y);
+        for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+            walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
+            used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.y);
+        }
     }
 }
 
@@ -551,6 +566,7 @@ struct MmArgs {
     int64_t nb, L, W, n_chunks;
     uint8_t* dirty;  // [chains][n_chunks] chunk must be run again although its start matches (k_mm_sweep)
     int64_t n_chains;
+    int64_t S;  // span of k_mm_warm2: chunks one speculative run walks through after its warm-up
 };
 
 // The min and the max are two independent recurrences and are treated as such: every launch of
@@ -569,27 +585,38 @@ constexpr int64_t MM_WARM_FULL = 12288;
 // (first half of the grid) WHILE the min runs its short one alone (second half), each at the speed
 // of a one-word step.
 __global__ __launch_bounds__(64) void k_mm_warm2(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    // SPAN as in k_ar_warm2: a run warms up before chunk g*S and walks on through the S-1 following
+    // chunks, leaving a start guess at every boundary it passes.  n_threads = chains * ceil(n_chunks / S).
     OFP_LATENCY_BOUND_KERNEL();
     const int64_t half = (n_threads + 63) / 64;  // blocks per half
     const bool is_min = blockIdx.x >= half;
     const int64_t id = ((int64_t)blockIdx.x - (is_min ? half : 0)) * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
-    const int64_t k = id % a.n_chunks;
-    const int64_t chain = id / a.n_chunks;
-    const int64_t start = k * a.L;
-    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    const int64_t n_groups = cdiv(a.n_chunks, a.S);
+    const int64_t g = id % n_groups;
+    const int64_t chain = id / n_groups;
+    const int64_t k0 = g * a.S;
+    const int64_t start = k0 * a.L;
     const float* rs = a.rel + chain * a.g.U;
     int norem = -1;
     if (!is_min) {
         const int64_t ws = max<int64_t>(start - a.W, 0);
         MaxStep mo{ws > 0 ? 0.0f : a.max0, a.ialpha_max, a.alpha_max};  // guessed from below
         walk<16, 0, false>(rs + ws, nullptr, start - ws, norem, mo);
-        used[sidx + 1] = ofp_f2u(mo.mx);
+        used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(mo.mx);
+        for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+            walk<16, 0, false>(rs + (k - 1) * a.L, nullptr, a.L, norem, mo);
+            used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(mo.mx);
+        }
     } else {
         const int64_t ws = max(max<int64_t>(start - a.W, 0), start - MM_WARM_FULL);
         MinStep mi{ws > 0 ? __builtin_inff() : a.min0, a.ialpha_min, a.alpha_min, a.minmin};  // from above
         walk<16, 0, false>(rs + ws, nullptr, start - ws, norem, mi);
-        used[sidx] = ofp_f2u(mi.mn);
+        used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(mi.mn);
+        for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+            walk<16, 0, false>(rs + (k - 1) * a.L, nullptr, a.L, norem, mi);
+            used[(chain * a.n_chunks + k) * 2] = ofp_f2u(mi.mn);
+        }
     }
 }
 
@@ -742,6 +769,8 @@ struct HpCand {
                       // from the true start state): lets a re-walk keep outputs whose start did not change
     int* counters;    // [0] chains with an unresolved chunk after the last resolve, [1] chains with
                       // unverified guesses
+    const int* prev;  // the counters of the preceding round, or NULL: both zero = the stage had converged,
+                      // this round (enqueued ahead of the host's check) has nothing to do
     int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
     unsigned long long* probe;  // diagnostics (OFP_HP_PROBE): per wave {start, end (s_memtime), HW_ID, XCC_ID}; else NULL
     __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
@@ -845,6 +874,7 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
 // pass B1: nxt[k][c][r_prev] for every chunk k >= 1 (parallel)
 __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_items) return;
     const int R1 = a.R + 1;
@@ -918,6 +948,7 @@ __global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items)
 // stuck at k until the next round.  Results stay exact; only the number of rounds changes.
 __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
     constexpr int SEG = 8, RT = 64 * SEG;       // chunks per lane, per tile
     constexpr int NV = HP_MAXR + 2, STUCK = HP_MAXR + 1;  // map domain: slots 0..R, STUCK
     __shared__ uint8_t tile[RT * (HP_MAXR + 1)];
@@ -1059,6 +1090,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
 // exact re-run has no such states and is run whole by lane 0.
 __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
@@ -1582,9 +1614,9 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R, hp_S, hp_span;
-    int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks;
+    int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks, ar_S;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
-    int64_t mm_L, mm_W, mm_chunks;
+    int64_t mm_L, mm_W, mm_chunks, mm_S;
     int tu;  // time steps per transpose tile
     // byte offsets
     int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
@@ -1658,6 +1690,30 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.hp_chunks = std::max<int64_t>(1, cdiv(g.V, l.hp_L));
     l.ar_chunks = std::max<int64_t>(1, cdiv(g.U, l.ar_L));
     l.mm_chunks = std::max<int64_t>(1, cdiv(g.U, l.mm_L));
+    // Span of the speculative warm-ups (k_ar_warm2 / k_mm_warm2): a run that walks on through S-1 more
+    // chunks after its warm-up costs (W + (S-1) L) / S samples per chunk instead of W, but is a longer
+    // dependent walk.  Model: the launch takes max(longest walk x time per step, bytes read / the rate
+    // scattered 16-byte streams sustain); the largest S within 10 % of the best estimate is taken (a lone
+    // clip stays latency-bound: S = 2; a batch reads up to 5x less).
+    auto pick_span = [&](int64_t user, int64_t W, int64_t L, int64_t n_chunks, double ns_per_step) -> int64_t {
+        if (user > 0) return std::min<int64_t>(user, std::max<int64_t>(n_chunks, 1));
+        double best = 1e300, t[5];
+        const int64_t cand[5] = {1, 2, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) {
+            const double walk = (double)(W + (cand[i] - 1) * L);
+            const double groups = (double)cdiv(n_chunks, cand[i]);
+            const double t_path = walk * ns_per_step * 1e-9;
+            const double t_mem = (double)chains * groups * walk * 4.0 / 3.0e12;
+            t[i] = std::max(t_path, t_mem);
+            best = std::min(best, t[i]);
+        }
+        int64_t S = 1;
+        for (int i = 0; i < 5; ++i)
+            if (t[i] <= 1.10 * best && cand[i] <= std::max<int64_t>(n_chunks, 1)) S = cand[i];
+        return S;
+    };
+    l.ar_S = l.ar_sym ? pick_span(d->t.ar_span, l.ar_W, l.ar_L, l.ar_chunks, 16.0) : 1;
+    l.mm_S = pick_span(d->t.mm_span, l.mm_W, l.mm_L, l.mm_chunks, 11.0);
     l.tu = (int)std::max<int64_t>(1, std::min<int64_t>(256, 8192 / g.C));
     int64_t o = 0;
     auto take = [&](int64_t bytes) {
@@ -1708,14 +1764,14 @@ struct Counters {
     int* base;
     int next;
     hipStream_t stream;
-    int take(int n, int** out) {  // n <= 2
-        if (next + n <= OFP_N_COUNTERS - 2) {
+    int take(int n, int** out) {  // n <= 16 consecutive zeroed slots
+        if (next + n <= OFP_N_COUNTERS - 16) {
             *out = base + next;
             next += n;
             return OFP_OK;
         }
-        *out = base + OFP_N_COUNTERS - 2;
-        OFP_HIP(hipMemsetAsync(*out, 0, 2 * sizeof(int), stream));
+        *out = base + OFP_N_COUNTERS - 16;
+        OFP_HIP(hipMemsetAsync(*out, 0, 16 * sizeof(int), stream));
         return OFP_OK;
     }
 };
@@ -1724,7 +1780,8 @@ struct Counters {
 // until a pass changes nothing.  used[] has been filled by the stage's warm-up kernels.
 template <class K, class A>
 int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
-               Counters& ctr, int* h_flags, int max_passes, hipStream_t stream, int64_t* passes, int64_t* repaired,
+               Counters& ctr, int* h_flags, int max_passes, int group, hipStream_t stream, int64_t* passes,
+               int64_t* repaired,
                void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, hipStream_t) = nullptr,
                int64_t words = 0) {
     if (words == 0) words = n_threads * 2;  // state words per array
@@ -1739,22 +1796,33 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
     if (n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
     uint32_t* prev = endA;
     uint32_t* next = endB;
-    for (int pass = 1;; ++pass) {
-        if (int rc = ctr.take(1, &d_changed)) return rc;
-        hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass, n_threads, (const uint32_t*)prev, next,
-                           used, d_changed);
+    // Verification passes are enqueued `group` at a time with ONE host synchronisation per group: a pass
+    // that finds nothing to repair costs microseconds on the GPU (every lane compares two words and
+    // copies its end state), a host round trip costs tens.  Converged = a pass of the group changed nothing.
+    group = std::max(1, std::min(group, 8));
+    for (int pass = 1;;) {
+        if (int rc = ctr.take(group, &d_changed)) return rc;
+        for (int q = 0; q < group; ++q) {
+            hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass + q, n_threads, (const uint32_t*)prev,
+                               next, used, d_changed + q);
+            std::swap(prev, next);
+        }
         OFP_LAUNCH_CHECK(name);
-        OFP_HIP(hipMemcpyAsync(h_flags, d_changed, sizeof(int), hipMemcpyDeviceToHost, stream));
+        OFP_HIP(hipMemcpyAsync(h_flags, d_changed, group * sizeof(int), hipMemcpyDeviceToHost, stream));
         OFP_HIP(hipStreamSynchronize(stream));
-        const int changed = h_flags[0];
-        std::swap(prev, next);
-        *passes += 1;
-        *repaired += changed;
+        int changed = 0;
+        for (int q = 0; q < group; ++q) {
+            changed = h_flags[q];
+            *passes += 1;
+            *repaired += changed;
+            if (changed == 0) break;
+        }
+        pass += group;
         if (changed == 0) break;
-        if (max_passes > 0 && pass >= max_passes)
-            return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name, changed, pass);
+        if (max_passes > 0 && pass > max_passes)
+            return ofp::fail(OFP_ERR_NOCONVERGE, "%s: %d chunks still changing after %d passes", name, changed, pass - 1);
         if (light_pass) {  // a cascade is under way: light passes, eight per host round trip
-            for (int group = 0; group < 4096; ++group) {
+            for (int grp = 0; grp < 4096; ++grp) {
                 if (int rc = ctr.take(1, &d_changed)) return rc;
                 for (int q = 0; q < 8; ++q) {
                     light_pass(args, n_threads, prev, next, used, d_changed, stream);
@@ -1957,6 +2025,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.counters = ctr.base;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         hc.probe = nullptr;
+        hc.prev = nullptr;
         const char* probe_path = do_cand ? getenv("OFP_HP_PROBE") : nullptr;
         const int64_t probe_waves = cdiv(chains * l.hp_chunks * (l.hp_R / l.hp_span), 64);
         if (probe_path) OFP_HIP(hipMalloc(&hc.probe, probe_waves * 32));
@@ -1999,22 +2068,35 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (phase == 1 || phase == 6) return OFP_OK;
         hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
         OFP_LAUNCH_CHECK("k_hp_plurality");
-        for (int it = 0;; ++it) {
-            if (int rc = ctr.take(2, &hc.counters)) return rc;
-            hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
-            OFP_LAUNCH_CHECK("k_hp_match");
-            hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
-            OFP_LAUNCH_CHECK("k_hp_resolve");
-            int* flags = d->h_flags;  // chains stuck at a break / chains with unverified guesses
-            OFP_HIP(hipMemcpyAsync(flags, hc.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
-            hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
-            OFP_LAUNCH_CHECK("k_hp_run");
+        // Verification rounds are enqueued a group at a time (three, then two) with ONE host synchronisation
+        // per group; a round whose predecessor left nothing unresolved returns at once (HpCand::prev).
+        const int* last = nullptr;
+        for (int it = 0;;) {
+            const int G = d->t.verify_group > 0 ? (int)std::min<int64_t>(d->t.verify_group, 8) : (it == 0 ? 3 : 2);
+            int* c = nullptr;
+            if (int rc = ctr.take(2 * G, &c)) return rc;
+            for (int q = 0; q < G; ++q) {
+                hc.counters = c + 2 * q;
+                hc.prev = last;
+                hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
+                hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
+                hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
+                last = hc.counters;
+            }
+            OFP_LAUNCH_CHECK("k_hp_match / k_hp_resolve / k_hp_run");
+            int* flags = d->h_flags;  // per round: chains stuck at a break, chains with unverified guesses
+            OFP_HIP(hipMemcpyAsync(flags, c, 2 * G * sizeof(int), hipMemcpyDeviceToHost, stream));
             OFP_HIP(hipStreamSynchronize(stream));
-            const int stuck = flags[0] + flags[1];
-            info[0] += 1;
-            info[3] += stuck;
+            int stuck = 0;
+            for (int q = 0; q < G; ++q) {
+                stuck = flags[2 * q] + flags[2 * q + 1];
+                info[0] += 1;
+                info[3] += stuck;
+                if (stuck == 0) break;
+            }
+            it += G;
             if (stuck == 0) break;
-            if (d->t.max_passes > 0 && it >= d->t.max_passes)
+            if (d->t.max_passes > 0 && it > d->t.max_passes)
                 return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
         }
     }
@@ -2041,6 +2123,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.Wc = l.ar_Wc;
         a.Wf = l.ar_Wf;
         a.n_chunks = l.ar_chunks;
+        a.S = l.ar_S;
         const int64_t nt = chains * l.ar_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
@@ -2056,14 +2139,15 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             OFP_LAUNCH_CHECK("k_ar_coarse");
         }
         if (l.ar_sym) {
-            hipLaunchKernelGGL(k_ar_warm2, dim3(2 * grid), dim3(64), 0, stream, a, nt, used);
+            const int64_t ntg = chains * cdiv(l.ar_chunks, l.ar_S);  // one run per group of S chunks
+            hipLaunchKernelGGL(k_ar_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_ar_warm2");
         } else {
             hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
             OFP_LAUNCH_CHECK("k_ar_warm");
         }
         int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
-                            stream, &info[1], &info[3]);
+                            d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &info[1], &info[3]);
         if (rc != OFP_OK) return rc;
     }
     OFP_HIP(hipEventRecord(ev[3], stream));
@@ -2094,14 +2178,18 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.W = l.mm_W;
         a.n_chunks = l.mm_chunks;
         a.n_chains = chains;
+        a.S = l.mm_S;
         a.dirty = reinterpret_cast<uint8_t*>(ws + l.o_mm_dirty);
         const int64_t nt = chains * l.mm_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
-        hipLaunchKernelGGL(k_mm_warm2, dim3(2 * grid), dim3(64), 0, stream, a, nt, used);
-        OFP_LAUNCH_CHECK("k_mm_warm2");
+        {
+            const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
+            hipLaunchKernelGGL(k_mm_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            OFP_LAUNCH_CHECK("k_mm_warm2");
+        }
         int rc = run_jacobi("tracker stage", k_mm_chunk, a, 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, ctr, d->h_flags,
-                            d->t.max_passes, stream, &info[2], &info[3],
+                            d->t.max_passes, d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &info[2], &info[3],
                             +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch,
                                 hipStream_t st) {
                                 const int64_t n = m.n_chains * m.n_chunks;
