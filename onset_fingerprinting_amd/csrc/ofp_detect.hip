@@ -1159,16 +1159,25 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
 __global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict__ xt, float* __restrict__ buf,
                                                  int64_t n_chains, int from_x, float floor_db) {
     const int64_t total = n_chains * g.U;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float v;
-        if (from_x) {
-            const int64_t chain = i / g.U, u = i - chain * g.U;
-            v = xt[chain * g.Nv + u_src_planar(g, u)];
-        } else {
-            v = buf[i];
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if (!from_x) {
+        // in place on the filtered stream: 16 bytes per lane and access (the work space is 256-byte aligned)
+        float4* b4 = reinterpret_cast<float4*>(buf);
+        const int64_t n4 = total >> 2;
+        for (int64_t i = tid0; i < n4; i += nthr) {
+            float4 v = b4[i];
+            v.x = ofp_rect_db(v.x, floor_db);
+            v.y = ofp_rect_db(v.y, floor_db);
+            v.z = ofp_rect_db(v.z, floor_db);
+            v.w = ofp_rect_db(v.w, floor_db);
+            b4[i] = v;
         }
-        buf[i] = ofp_rect_db(v, floor_db);
+        for (int64_t i = (n4 << 2) + tid0; i < total; i += nthr) buf[i] = ofp_rect_db(buf[i], floor_db);
+        return;
+    }
+    for (int64_t i = tid0; i < total; i += nthr) {
+        const int64_t chain = i / g.U, u = i - chain * g.U;
+        buf[i] = ofp_rect_db(xt[chain * g.Nv + u_src_planar(g, u)], floor_db);
     }
 }
 
@@ -1182,16 +1191,54 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     const int64_t u0 = (int64_t)blockIdx.x * TU;
     const int nt = (int)min<int64_t>(TU, g.U - u0);
     const int total = nt * C;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int c = i / nt, t = i - c * nt;
-        float* p = buf + (clip * C + c) * g.U + u0 + t;
-        const float v = ofp_rel_linear(*p, floor_db);
-        *p = v;
-        tile[c * (TU + 1) + t] = v;
+    // 16-byte accesses on both sides whenever the geometry keeps them aligned (it does for every block size
+    // that is a multiple of 4): the planar series in steps of 4 samples, the interleaved output in steps of
+    // 4 floats of its [time][channel] order
+    const bool vec = (g.U & 3) == 0 && (TU & 3) == 0 && (nt & 3) == 0 && ((g.n_wb * C) & 3) == 0 &&
+                     (((int64_t)TU * C) & 3) == 0 && ((g.Nm * C) & 3) == 0;
+    if (vec) {
+        const int q = nt >> 2;  // float4 groups per channel row
+        for (int i = threadIdx.x; i < q * C; i += 256) {
+            const int c = i / q, t = (i - c * q) << 2;
+            float4* p = reinterpret_cast<float4*>(buf + (clip * C + c) * g.U + u0 + t);
+            float4 v = *p;
+            v.x = ofp_rel_linear(v.x, floor_db);
+            v.y = ofp_rel_linear(v.y, floor_db);
+            v.z = ofp_rel_linear(v.z, floor_db);
+            v.w = ofp_rel_linear(v.w, floor_db);
+            *p = v;
+            float* tl = tile + c * (TU + 1) + t;
+            tl[0] = v.x; tl[1] = v.y; tl[2] = v.z; tl[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int c = i / nt, t = i - c * nt;
+            float* p = buf + (clip * C + c) * g.U + u0 + t;
+            const float v = ofp_rel_linear(*p, floor_db);
+            *p = v;
+            tile[c * (TU + 1) + t] = v;
+        }
     }
     if (!rel_out) return;
     __syncthreads();
     float* dst = rel_out + clip * g.Nm * C;
+    const int64_t m0 = u0 - g.n_wb;  // main-part row of this tile's first time step (tiles do not straddle n_wb
+                                     // unless TU does not divide it: those take the scalar path)
+    if (vec && (m0 >= 0 || m0 + nt <= 0) && (reinterpret_cast<uintptr_t>(rel_out) & 15u) == 0) {
+        if (m0 < 0) return;
+        float4* d4 = reinterpret_cast<float4*>(dst + m0 * C);
+        for (int i = threadIdx.x; i < (total >> 2); i += 256) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * i + e;
+                const int t = j / C, c = j - t * C;
+                o[e] = tile[c * (TU + 1) + t];
+            }
+            d4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < total; i += 256) {
         const int t = i / C, c = i - t * C;
         const int64_t m = u0 + t - g.n_wb;
@@ -1664,6 +1711,12 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // load instead of 16 and no lane runs much longer than W + L.  < 0: common start, see kernel.
     l.hp_delta = d->t.hp_candidate_offset < 0 ? 0 : pick(d->t.hp_candidate_offset, 8);
     l.hp_span = (d->t.hp_span == 2 || d->t.hp_span == 4) && l.hp_R % (int)d->t.hp_span == 0 ? (int)d->t.hp_span : 1;
+    // Unset: a candidates launch of more than about one wave per SIMD is throughput-bound, and sharing a
+    // warm-up between two chunks then does 2/3 of the steps in half the waves (measured, detector only:
+    // 8 x C2 10.2 -> 8.9 ms, C4 36.6 -> 31.7 ms); a lone clip (720 waves) stays at 1, the latency setting.
+    if (d->t.hp_span <= 0 && l.hp_R % 2 == 0 &&
+        chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * d->n_cus)
+        l.hp_span = 2;
     l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
     l.ar_L = pick(d->t.ar_chunk, arL);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
