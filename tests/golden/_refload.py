@@ -36,7 +36,29 @@ def _pad_center(data, *, size, axis=-1, **kwargs):
     return np.pad(data, lengths, **kwargs)
 
 
-def _install_placeholders():
+class _RingStandIn:
+    """STAND-IN for loopmate.circular_array.CircularArray (absent, not vendored), generator side only, for
+    the backtracking fixture g18: the three things detection.py uses (:719-721 constructor on an array,
+    :756 write(block), :802-803 .N and [-N:] = the last N rows, oldest first).  The reference backs it
+    with np.empty (uninitialised rows before the ring has filled); the stand-in zeroes them so that the
+    fixture is deterministic.  Because this is OUR reading of the absent class, the Python backtracking
+    loop bound stays "parity unpinned"  -- the fixture pins everything else of
+    that code path (the loop at detection.py:806-824 itself is the reference's own code, executed)."""
+
+    def __init__(self, data, *a, **k):
+        self.data = data
+        self.data[...] = 0
+        self.N = data.shape[0]
+
+    def write(self, x):
+        n = len(x)
+        self.data = np.concatenate([self.data[n:], np.asarray(x, dtype=self.data.dtype)])[-self.N:]
+
+    def __getitem__(self, idx):
+        return self.data[idx]
+
+
+def _install_placeholders(ring_stand_in=False):
     def mod(name):
         m = types.ModuleType(name)
         sys.modules[name] = m
@@ -61,7 +83,7 @@ def _install_placeholders():
             def __init__(self, *a, **k):
                 raise RuntimeError("loopmate is not available")
 
-        ca.CircularArray = CircularArray
+        ca.CircularArray = _RingStandIn if ring_stand_in else CircularArray
         loopmate.circular_array = ca
     class _Anything(types.ModuleType):
         # module-level constants in data.py instantiate augmentation objects
@@ -80,11 +102,12 @@ def _install_placeholders():
         L.LightningModule = torch.nn.Module
 
 
-def load_reference():
-    """Returns the reference package modules (detection, data, model, calibration)."""
+def load_reference(ring_stand_in=False):
+    """Returns the reference package modules (detection, data, model, calibration).
+    ring_stand_in: make ``backtrack=True`` runnable with the ring-buffer stand-in above (g18 only)."""
     if not (REF_SO_DIR / "envelope_follower.so").exists():
         raise RuntimeError("run `make -C oracle ref` first")
-    _install_placeholders()
+    _install_placeholders(ring_stand_in)
     if str(REF_ROOT) not in sys.path:
         sys.path.insert(0, str(REF_ROOT))
     sys.dont_write_bytecode = True

@@ -270,3 +270,45 @@ def test_init_is_refused_where_the_reference_reads_past_its_buffers(det):
         d.init(np.zeros((48000 * 2 // 256 * 256, 2), np.float32))
     with pytest.raises(ctypes.ArgumentError):
         det.AmplitudeOnsetDetector(2, 128, sr=48000).init(np.zeros((96000, 2), np.float64))
+
+
+def test_g17_realtime_sets_on_the_gpu(det):
+    """The realtime arguments (realtime/audio.py:39-52: no high-pass, slow follower 8000/8000, thresholds
+    0.45/0.45, block 128 @ 96 kHz, 3 channels) at fast attacks >= 1 sample: GPU == the reference's golden
+    indices, offline and per block."""
+    from tests.golden.make_golden_r2_cfg import G17_CASES, RT
+    from tests.test_oracle_golden import _stream_records
+    g = load_golden("g17_realtime_sets")
+    for name, (kw, sr, B) in G17_CASES.items():
+        x = synth.drum_hits(3, 4.0, sr, seed=170 + len(name), period=0.37)
+        recs, rel, _ = det.detect_batch(x[None], block_size=B, sr=sr, **RT, **kw)
+        assert np.array_equal(recs[0]["channel"], g[f"{name}_ch"]) and np.array_equal(recs[0]["sample"], g[f"{name}_on"])
+        np.testing.assert_allclose(rel[0][::211], g[f"{name}_rel"], rtol=2e-5, atol=1e-6)
+    kw, sr, B = G17_CASES["a3"]
+    x = synth.drum_hits(3, 1.5, sr, seed=177, period=0.21)
+    got = _stream_records(lambda: det.AmplitudeOnsetDetector(3, B, sr=sr, **RT, **kw), x, B, int(0.1 * sr))
+    assert np.array_equal(got, g["blk_records"])
+
+
+def test_realtime_set_against_the_reference_golden_on_the_gpu(det):
+    """fast_ar = (0.3, 800) on the g4 input: from the first second on the GPU's records equal the
+    reference's golden rt_ch / rt_on; below it the documented, COUNTED deviation (RT_CHAOTIC)."""
+    from tests.golden.make_golden_r2_cfg import RT_CHAOTIC
+    from tests.test_oracle_golden import realtime_deviation
+    g = load_golden("g4_end_to_end")
+    x2 = synth.c2_drums(10.0, 8, SR, seed=1)
+    recs, _, _ = det.detect_batch(x2[None, :, :3].copy(), block_size=128, sr=SR, hipass_freq=0, fast_ar=(0.3, 800.0),
+                                  slow_ar=(8000.0, 8000.0), on_threshold=0.45, off_threshold=0.45, cooldown=9600)
+    assert realtime_deviation(recs[0]["channel"].astype(np.int64), recs[0]["sample"], g, SR) == RT_CHAOTIC
+
+
+def test_g18_python_backtracking_on_the_gpu(det):
+    """backtrack=True per block through the streaming kernels: the records equal what the reference's
+    Python loop gives on the ring-buffer stand-in (parity of the loop bound: unpinned, see the oracle test)."""
+    from tests.golden.make_golden_r2_cfg import G18_CASES
+    from tests.test_oracle_golden import _stream_records
+    g = load_golden("g18_backtrack_py")
+    for name, (kw, C, B) in G18_CASES.items():
+        x = synth.drum_hits(C, 2.0, SR, seed=180 + C + B, period=0.19)
+        got = _stream_records(lambda: det.AmplitudeOnsetDetector(C, B, sr=SR, **kw), x, B, 4800)
+        assert np.array_equal(got, g[f"{name}_records"]), name

@@ -276,3 +276,72 @@ def test_init_is_refused_where_the_reference_reads_past_its_buffers():
     d = oracle.OracleDetector(2, 128, sr=48000)
     with pytest.raises(ValueError):
         d.init(np.zeros((128 * 100, 2), np.float32))  # shorter than the settling blocks / one second
+
+
+def _stream_records(det_factory, x, B, warm):
+    od = det_factory()
+    od.init_minmax_tracker(x[:warm])
+    recs = []
+    for i in range(len(x) // B):
+        c, d, r = od(np.ascontiguousarray(x[i * B:(i + 1) * B]))
+        recs += [(i, int(a), int(b)) for a, b in zip(c, d)]
+    return np.array(recs, np.int64).reshape(-1, 3)
+
+
+def test_g17_realtime_sets_are_reproduced_exactly():
+    """The realtime arguments of realtime/audio.py:39-52 at fast attacks >= 1 sample (not rounding-chaotic):
+    onset indices equal the reference's, offline and per block."""
+    from onset_fingerprinting_amd import synth
+    from tests.golden.make_golden_r2_cfg import G17_CASES, RT
+    g = load_golden("g17_realtime_sets")
+    for name, (kw, sr, B) in G17_CASES.items():
+        x = synth.drum_hits(3, 4.0, sr, seed=170 + len(name), period=0.37)
+        assert x.astype(np.float64).sum() == g[f"{name}_xsum"], "synthetic generator drifted"
+        c, o, rel = oracle.detect_onsets_amplitude(x, block_size=B, sr=sr, **RT, **kw)
+        assert np.array_equal(np.array(c), g[f"{name}_ch"]) and np.array_equal(np.array(o), g[f"{name}_on"]), name
+        assert len(c) >= 30
+        np.testing.assert_allclose(rel[::211], g[f"{name}_rel"], rtol=2e-5, atol=1e-6)
+    kw, sr, B = G17_CASES["a3"]
+    x = synth.drum_hits(3, 1.5, sr, seed=177, period=0.21)
+    assert x.astype(np.float64).sum() == g["blk_xsum"]
+    got = _stream_records(lambda: oracle.OracleDetector(3, B, sr=sr, **RT, **kw), x, B, int(0.1 * sr))
+    assert np.array_equal(got, g["blk_records"]) and len(got) >= 20
+
+
+def test_realtime_set_deviation_is_counted():
+    """fast_ar = (0.3, 800): rounding-chaotic below the first hit (tests/golden/make_golden_r2_cfg.py
+    RT_CHAOTIC).  The count of differing records is pinned so that a change shows."""
+    from onset_fingerprinting_amd import synth
+    from tests.golden.make_golden_r2_cfg import RT_CHAOTIC
+    g = load_golden("g4_end_to_end")
+    sr = 48000
+    x2 = synth.c2_drums(10.0, 8, sr, seed=1)
+    c, o, _ = oracle.detect_onsets_amplitude(x2[:, :3].copy(), block_size=128, hipass_freq=0, fast_ar=(0.3, 800.0),
+                                             slow_ar=(8000.0, 8000.0), on_threshold=0.45, off_threshold=0.45,
+                                             cooldown=9600, sr=sr)
+    assert realtime_deviation(np.array(c), np.array(o), g, sr) == RT_CHAOTIC
+
+
+def realtime_deviation(c, o, g, sr):
+    ours = set(zip(c[o < sr].tolist(), o[o < sr].tolist()))
+    ref = set(zip(g["rt_ch"][g["rt_on"] < sr].tolist(), g["rt_on"][g["rt_on"] < sr].tolist()))
+    keep, gkeep = o >= sr, g["rt_on"] >= sr
+    assert np.array_equal(c[keep], g["rt_ch"][gkeep]) and np.array_equal(o[keep], g["rt_on"][gkeep])
+    return dict(below_sr_reference=len(ref), below_sr_canon=len(ours), below_sr_common=len(ours & ref),
+                from_sr_on=int(keep.sum()))
+
+
+def test_g18_python_backtracking_with_the_ring_stand_in():
+    """AmplitudeOnsetDetector(backtrack=True).__call__ per block: the reference's own Python loop
+    (detection.py:800-825) on the ring-buffer STAND-IN for loopmate.CircularArray (absent): the loop bound
+    stays "parity unpinned" (the stand-in is our reading of that class), everything else of the path is
+    the reference's code.  Not covered, because the reference raises IndexError there: an onset at
+    delta 0 with backtrack_buffer_size == block_size (buffer[-(B + 1)], detection.py:812-813)."""
+    from onset_fingerprinting_amd import synth
+    from tests.golden.make_golden_r2_cfg import G18_CASES
+    g = load_golden("g18_backtrack_py")
+    for name, (kw, C, B) in G18_CASES.items():
+        x = synth.drum_hits(C, 2.0, 48000, seed=180 + C + B, period=0.19)
+        assert x.astype(np.float64).sum() == g[f"{name}_xsum"]
+        got = _stream_records(lambda: oracle.OracleDetector(C, B, sr=48000, **kw), x, B, 4800)
+        assert np.array_equal(got, g[f"{name}_records"]) and len(got) >= 18, name
