@@ -393,6 +393,25 @@ int ofp_group_windows(const float* d_x, int64_t n_clips, int64_t n_samples, int3
 int ofp_xcorr_lag(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n_in, int32_t d, int32_t take_abs,
                   int32_t cutoff, const int32_t* d_lo, const int32_t* d_hi, int32_t* d_argmax, float* d_cc,
                   int32_t cc_stride, void* stream);
+/* adjust_onset (detection.py:299-352) for a batch of pairs, one wave each: d_x, d_y [n_pairs][n] float32,
+ * d_onsets [n_pairs][2] (onset in x, onset in y), d_new_lag [n_pairs] -> d_moves [n_pairs][2], the amounts
+ * the reference returns to be added to the two onsets.  Weighted sums in fp64 as in ofp_fix_onsets. */
+int ofp_adjust_onset(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n, const int32_t* d_onsets,
+                     const int32_t* d_new_lag, int32_t* d_moves, void* stream);
+/* filter_data (detection.py:355-370): d_y[t][c] = d_x[t][c], or 0 where the first difference along time is
+ * negative (direction 1, "up") / positive (direction 2, "down"); row 0 is kept.  Not in place. */
+int ofp_filter_direction(const float* d_x, int64_t n, int32_t n_channels, int32_t direction, float* d_y, void* stream);
+/* detect_onset_region (detection.py:454-484) for n_onsets onsets of one 1-D signal d_audio [n_audio]:
+ * region = audio[onset - n/2 : onset + n/2] (clipped), |.|, scipy medfilt (zero-padded, odd size <= 33),
+ * threshold_factor * max, binary_opening with ones(5), first True -> d_out [n_onsets] absolute indices.
+ * n/2*2 <= 4096. */
+int ofp_onset_region(const float* d_audio, int64_t n_audio, const int64_t* d_onsets, int64_t n_onsets, int32_t n,
+                     int32_t median_filter_size, float threshold_factor, int64_t* d_out, void* stream);
+/* StretchFrameExtractor's resampling (data.py:212-222): scipy.signal.resample (Fourier method, real input) of
+ * the windows audio[d_start[i] : d_start[i] + d_nx[i], c] to `num` samples each: d_out [n_items][C][num].
+ * d_audio [n_samples][C]; samples outside the clip read as 0; d_nx[i] <= max_nx <= 2048, num <= 2048. */
+int ofp_resample_windows(const float* d_audio, int64_t n_samples, int32_t n_channels, const int64_t* d_start,
+                         const int32_t* d_nx, int64_t n_items, int32_t max_nx, int32_t num, float* d_out, void* stream);
 /* Full cross-correlation of row pairs (batch_cc, data.py:226-230; paired_xcorr, model.py:12-45):
  * d_out[i][j] = sum_t a[i][t + j - (L-1)] b[i][t], j in [0, 2L-1); rows i of d_a / d_b start at
  * i*a_stride / i*b_stride floats.  mean_k > 1: output row i is the mean of input rows

@@ -145,6 +145,10 @@ SIGNATURES = {
     "ofp_group_windows": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp,
                                          _vp]),
     "ofp_xcorr_lag": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ofp_adjust_onset": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ofp_filter_direction": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "ofp_onset_region": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "ofp_resample_windows": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_xcorr_full": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp]),
     "ofp_spectral_flux": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "ofp_select_rank": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),

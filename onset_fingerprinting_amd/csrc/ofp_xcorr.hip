@@ -158,6 +158,89 @@ __global__ __launch_bounds__(XT) void k_xcorr_full(const float* __restrict__ a, 
     }
 }
 
+// adjust_onset (detection.py:299-352) for one pair, executed by one wave: which of the two onsets moves to
+// make their lag `new_lag`, decided by the exponentially weighted signal between the old and the new
+// position (weights np.exp(np.linspace(0, -e, |lag_diff|)), sums in fp64 as np.sum of the float64
+// products, normalised by the signals' maxima mx / my).  *ca / *cb: what to add to onset 0 / onset 1
+// (valid on lane 0).
+__device__ __forceinline__ void adjust_onset_wave(const float* xs, const float* ys, int n, int o0, int o1, int new_lag,
+                                                  float mx, float my, int lane, int64_t* ca, int64_t* cb) {
+    const int lag_diff = (o1 - o0) - new_lag;
+    const int k = lag_diff < 0 ? -lag_diff : lag_diff;
+    int x_start, x_end, y_start, y_end;
+    if (lag_diff < 0) {
+        x_start = max(o0 + lag_diff, 0);
+        x_end = min(o0, n);
+        y_start = min(o1, n);
+        y_end = min(o1 - lag_diff, n);
+    } else {
+        x_start = o0;
+        x_end = min(o0 + lag_diff, n);
+        y_start = max(o1 - lag_diff, 0);
+        y_end = min(o1, n);
+    }
+    x_start = max(0, min(x_start, n));
+    y_start = max(0, min(y_start, n));
+    // weights np.exp(np.linspace(0, -e, k)): w[m] = exp(m * (-e / (k - 1))), w[k-1] = exp(-e)
+    const double step = k > 1 ? -2.718281828459045 / (double)(k - 1) : 0.0;
+    const int Lx = x_end - x_start, Ly = y_end - y_start;
+    double sa = 0.0, sb = 0.0;
+    for (int q = lane; q < Lx; q += XW) {
+        int m = k - Lx + q;
+        double w = exp(m == k - 1 && k > 1 ? -2.718281828459045 : (double)m * step);
+        sa += (double)xs[x_start + q] * w;
+    }
+    for (int q = lane; q < Ly; q += XW) {
+        int m = k - 1 - q;
+        double w = exp(m == k - 1 && k > 1 ? -2.718281828459045 : (double)m * step);
+        sb += (double)ys[y_start + q] * w;
+    }
+    for (int o = XW / 2; o > 0; o >>= 1) {
+        sa += __shfl_xor(sa, o);
+        sb += __shfl_xor(sb, o);
+    }
+    const double da = Lx > 0 ? sa / (double)mx : 0.0;
+    const double db = Ly > 0 ? sb / (double)my : 0.0;
+    if (da > db) {
+        if (o0 + lag_diff < 0) {
+            *ca = 0;
+            *cb = -lag_diff;
+        } else {
+            *ca = lag_diff;
+            *cb = 0;
+        }
+    } else {
+        *ca = 0;
+        *cb = -lag_diff;
+    }
+}
+
+// adjust_onset for a batch of pairs, one wave per pair: x, y [P][n] rows, onsets [P][2], new_lag [P] ->
+// moves [P][2] (what the reference returns: the amounts to add to the two onsets).
+__global__ __launch_bounds__(XW) void k_adjust_onset(const float* __restrict__ x, const float* __restrict__ y, int n,
+                                                     const int32_t* __restrict__ onsets,
+                                                     const int32_t* __restrict__ new_lag, int32_t* __restrict__ moves) {
+    const int64_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* xs = x + p * n;
+    const float* ys = y + p * n;
+    float mx = -INFINITY, my = -INFINITY;
+    for (int i = lane; i < n; i += XW) {
+        mx = fmaxf(mx, xs[i]);
+        my = fmaxf(my, ys[i]);
+    }
+    for (int o = XW / 2; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        my = fmaxf(my, __shfl_xor(my, o));
+    }
+    int64_t ca = 0, cb = 0;
+    adjust_onset_wave(xs, ys, n, onsets[2 * p], onsets[2 * p + 1], new_lag[p], mx, my, lane, &ca, &cb);
+    if (lane == 0) {
+        moves[2 * p] = (int32_t)ca;
+        moves[2 * p + 1] = (int32_t)cb;
+    }
+}
+
 // ---- fix_onsets ---------------------------------------------------------------------------
 struct FixArgs {
     const float* audio;  // [n_clips][N][C]
@@ -296,57 +379,10 @@ __global__ __launch_bounds__(XT) void k_fix_onsets(FixArgs A) {
         if (am >= 0) {
             const int new_lag = current_lag + A.tol - am;
             // adjust_onset (detection.py:310-352)
-            const int lag_diff = current_lag - new_lag;
-            const int k = lag_diff < 0 ? -lag_diff : lag_diff;
-            int x_start, x_end, y_start, y_end;
-            if (lag_diff < 0) {
-                x_start = max(o0 + lag_diff, 0);
-                x_end = min(o0, n);
-                y_start = min(o1, n);
-                y_end = min(o1 - lag_diff, n);
-            } else {
-                x_start = o0;
-                x_end = min(o0 + lag_diff, n);
-                y_start = max(o1 - lag_diff, 0);
-                y_end = min(o1, n);
-            }
-            x_start = max(0, min(x_start, n));
-            y_start = max(0, min(y_start, n));
             if (wave == 0) {
-                // weights np.exp(np.linspace(0, -e, k)): w[m] = exp(m * (-e / (k - 1))), w[k-1] = exp(-e)
-                const double step = k > 1 ? -2.718281828459045 / (double)(k - 1) : 0.0;
-                const int Lx = x_end - x_start, Ly = y_end - y_start;
-                double sa = 0.0, sb = 0.0;
-                for (int q = lane; q < Lx; q += XW) {
-                    int m = k - Lx + q;
-                    double w = exp(m == k - 1 && k > 1 ? -2.718281828459045 : (double)m * step);
-                    sa += (double)xs[x_start + q] * w;
-                }
-                for (int q = lane; q < Ly; q += XW) {
-                    int m = k - 1 - q;
-                    double w = exp(m == k - 1 && k > 1 ? -2.718281828459045 : (double)m * step);
-                    sb += (double)ys[y_start + q] * w;
-                }
-                for (int o = XW / 2; o > 0; o >>= 1) {
-                    sa += __shfl_xor(sa, o);
-                    sb += __shfl_xor(sb, o);
-                }
+                int64_t ca, cb;
+                adjust_onset_wave(xs, ys, n, o0, o1, new_lag, mx, my, lane, &ca, &cb);
                 if (lane == 0) {
-                    double da = Lx > 0 ? sa / (double)mx : 0.0;
-                    double db = Ly > 0 ? sb / (double)my : 0.0;
-                    int64_t ca, cb;
-                    if (da > db) {
-                        if (o0 + lag_diff < 0) {
-                            ca = 0;
-                            cb = -lag_diff;
-                        } else {
-                            ca = lag_diff;
-                            cb = 0;
-                        }
-                    } else {
-                        ca = 0;
-                        cb = -lag_diff;
-                    }
                     og[c0] += ca;
                     og[c1] += cb;
                 }
@@ -361,6 +397,17 @@ __global__ __launch_bounds__(XT) void k_fix_onsets(FixArgs A) {
 }  // namespace
 
 extern "C" {
+
+int ofp_adjust_onset(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n, const int32_t* d_onsets,
+                     const int32_t* d_new_lag, int32_t* d_moves, void* stream) {
+    if (n_pairs == 0) return OFP_OK;
+    OFP_REQUIRE(d_x && d_y && d_onsets && d_new_lag && d_moves, "ofp_adjust_onset: NULL argument");
+    OFP_REQUIRE(n_pairs > 0 && n_pairs < (1ll << 31) && n >= 1, "ofp_adjust_onset: bad size");
+    hipLaunchKernelGGL(k_adjust_onset, dim3((unsigned)n_pairs), dim3(XW), 0, (hipStream_t)stream, d_x, d_y, n, d_onsets,
+                       d_new_lag, d_moves);
+    OFP_LAUNCH_CHECK("k_adjust_onset");
+    return OFP_OK;
+}
 
 int ofp_xcorr_lag(const float* d_x, const float* d_y, int64_t n_pairs, int32_t n_in, int32_t d, int32_t take_abs,
                   int32_t cutoff, const int32_t* d_lo, const int32_t* d_hi, int32_t* d_argmax, float* d_cc,

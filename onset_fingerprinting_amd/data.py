@@ -370,6 +370,42 @@ class FrameExtractor:
         return out if a.ndim == 2 else out[:, 0, :]
 
 
+class StretchFrameExtractor(FrameExtractor):
+    """data.py:195-223: windows of frame_length + shift samples (random shift per onset, drawn with the
+    reference's own np.random calls, so a seeded run draws the same shifts) resampled to frame_length with
+    scipy.signal.resample's Fourier method -- on the GPU (``ofp_resample_windows``)."""
+
+    def __init__(self, frame_length: int, pre_samples: int, max_stretch: float = 0.03, use_min_onset=True, device=0):
+        super().__init__(frame_length, pre_samples, device=device)
+        if not use_min_onset:
+            raise NotImplementedError("use_min_onset=False not supported yet!")
+        self.max_shift = int(self.frame_length * max_stretch)
+
+    def __call__(self, audio, onsets):
+        onsets = np.asarray(onsets)
+        shifts = np.random.randint(1, self.max_shift, len(onsets))       # data.py:208-209
+        shifts *= np.random.choice((-1, 1), size=len(shifts))
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        two_d = a.ndim == 2
+        starts = (onsets.min(axis=1) if two_d else onsets).astype(np.int64) - self.pre_samples
+        nx = (self.frame_length + shifts).astype(np.int32)
+        if len(starts) and (starts.min() < 0 or (starts + nx).max() > len(a)):
+            raise ValueError("StretchFrameExtractor: a window leaves the audio (the reference's slice would be "
+                             "shorter than frame_length + shift there)")
+        dev = _device(self.device)
+        a2 = a if two_d else a[:, None]
+        C = a2.shape[1]
+        out = torch.empty((len(starts), C, self.frame_length), dtype=torch.float32, device=dev)
+        if len(starts):
+            xd = torch.from_numpy(a2).to(dev).contiguous()
+            check(_lib.lib().ofp_resample_windows(xd.data_ptr(), a2.shape[0], C, torch.from_numpy(starts).to(dev).data_ptr(),
+                                                  torch.from_numpy(nx).to(dev).data_ptr(), len(starts), int(nx.max()),
+                                                  self.frame_length, out.data_ptr(), _stream(dev)),
+                  "ofp_resample_windows")
+        res = out.cpu().numpy()
+        return res if two_d else res[:, 0, :]
+
+
 class FastFrameExtractor:
     """data.py:123-192: holds the audio (in HBM) and the onsets, always starts a frame at the minimum
     onset of its group, and returns a torch tensor ``[O, C, W]`` (``[O, W]`` for 1-D audio) from

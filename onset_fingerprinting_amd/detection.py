@@ -400,6 +400,81 @@ def fix_onsets(audio: np.ndarray, onsets: np.ndarray, filter_size: int = 5, d: i
     return o.cpu().numpy().astype(np.asarray(onsets).dtype, copy=False)
 
 
+def adjust_onset_rel(onsets, relx: np.ndarray, rely: np.ndarray, new_lag: int):
+    """detection.py:271-296: adjust one onset of a pair to a target lag by comparing four samples of the
+    two relative envelopes -- index logic on the caller's arrays, no sample pass (host, like
+    `window_contribution_weights`)."""
+    oa, ob = onsets[0], onsets[1]
+    lag_diff = (ob - oa) - new_lag
+    da = relx[oa + lag_diff] - relx[oa]
+    db = rely[ob - lag_diff] - rely[ob]
+    if da > db:
+        oa += lag_diff
+    else:
+        ob -= lag_diff
+    return oa, ob
+
+
+def adjust_onsets_device(x, y, onsets, new_lag):
+    """Batched `adjust_onset`: x, y float32 CUDA [P, n]; onsets int32 CUDA [P, 2]; new_lag int32 CUDA [P]
+    -> moves int32 [P, 2] (the amounts to add to the two onsets), one wave per pair."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and y.shape == x.shape and y.is_contiguous()
+    P, n = x.shape
+    moves = torch.empty((P, 2), dtype=torch.int32, device=x.device)
+    check(_lib.lib().ofp_adjust_onset(x.data_ptr(), y.data_ptr(), P, n, onsets.data_ptr(), new_lag.data_ptr(),
+                                      moves.data_ptr(), _stream_ptr(x.device)), "ofp_adjust_onset")
+    return moves
+
+
+def adjust_onset(onsets, x: np.ndarray, y: np.ndarray, new_lag: int, device=0):
+    """detection.py:299-352: same arguments, returns the pair (move of onset x, move of onset y)."""
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)[None]).to(dev)
+    yd = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)[None]).to(dev)
+    m = adjust_onsets_device(xd, yd, torch.tensor([[int(onsets[0]), int(onsets[1])]], dtype=torch.int32, device=dev),
+                             torch.tensor([int(new_lag)], dtype=torch.int32, device=dev)).cpu().numpy()[0]
+    return int(m[0]), int(m[1])
+
+
+def filter_data(x: np.ndarray, direction: str, device=0) -> np.ndarray:
+    """detection.py:355-370: nulls, IN PLACE like the reference, every sample whose first difference along
+    axis 0 is negative ("up") / positive ("down"); returns x."""
+    if direction not in ("up", "down"):
+        raise RuntimeError(f"Unknown onset direction {direction=}!")
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    n = a.shape[0] if a.ndim else 0
+    cols = int(a.size // max(n, 1)) if n else 1
+    xd = torch.from_numpy(a.reshape(n, cols)).to(dev)
+    yd = torch.empty_like(xd)
+    check(_lib.lib().ofp_filter_direction(xd.data_ptr(), n, cols, 1 if direction == "up" else 2, yd.data_ptr(),
+                                          _stream_ptr(dev)), "ofp_filter_direction")
+    x[...] = yd.cpu().numpy().reshape(a.shape)
+    return x
+
+
+def detect_onset_regions_device(audio, onsets, n=256, median_filter_size=5, threshold_factor=0.5):
+    """Batched `detect_onset_region`: audio float32 CUDA [N] (1-D), onsets int64 CUDA [K] -> int64 [K]."""
+    assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 1 and audio.is_contiguous()
+    out = torch.empty(onsets.shape[0], dtype=torch.int64, device=audio.device)
+    check(_lib.lib().ofp_onset_region(audio.data_ptr(), audio.shape[0], onsets.data_ptr(), onsets.shape[0], int(n),
+                                      int(median_filter_size), float(threshold_factor), out.data_ptr(),
+                                      _stream_ptr(audio.device)), "ofp_onset_region")
+    return out
+
+
+def detect_onset_region(audio, detected_onset, n=256, median_filter_size=5, threshold_factor=0.5, device=0):
+    """detection.py:454-484: in the |audio| around the onset, the start of the loud part (median filter,
+    threshold at `threshold_factor` of its maximum, binary opening, first True)."""
+    dev = _dev(device)
+    _lib.require_gpu(dev.index or 0)
+    a = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32).reshape(-1)).to(dev)
+    o = torch.tensor([int(detected_onset)], dtype=torch.int64, device=dev)
+    return int(detect_onset_regions_device(a, o, n, median_filter_size, threshold_factor).cpu()[0])
+
+
 def detect_onsets(x: np.ndarray, sr: int = 96000, method="amp"):
     """detection.py:12-16."""
     if method == "amp":

@@ -27,15 +27,18 @@ from .detector import (  # noqa: F401
 from .spectral import (  # noqa: F401
     cspec_to_mfcc,
     dense_power_frames,
+    fourier_resample,
     frame_extract,
     hann_periodic,
     mel_filterbank,
     power_to_db,
     stft,
     stft_frame,
+    stretch_frames,
     window_contribution_weights,
 )
 from .classifier import cccnn_forward, cnn_forward, fcnn_forward  # noqa: F401
 from .groups import find_onset_groups, group_windows  # noqa: F401
-from .xcorr import adjust_onset, cross_correlation_lag, fix_onsets, lag_window, xcorr_slice  # noqa: F401
+from .xcorr import (adjust_onset, adjust_onset_rel, cross_correlation_lag, detect_onset_region,  # noqa: F401
+                    filter_data, fix_onsets, lag_window, xcorr_slice)
 from .spectral_onsets import detect_onsets_spectral, librosa_stft_mag, peak_pick  # noqa: F401

@@ -161,3 +161,41 @@ def cspec_to_mfcc(S, sr, fmin=0, fmax=None, n_mels=40, n_mfcc=14):
     mels = np.einsum("...ft,mf->...mt", P, fb)
     db = power_to_db(mels)
     return scipy.fft.dct(db, axis=-2, type=2, norm="ortho")[..., :n_mfcc, :]
+
+
+def fourier_resample(x, num):
+    """scipy.signal.resample (real input, time domain, no window) restated with explicit DFT sums in fp64:
+    keep the bins up to the Nyquist of the shorter length (doubling / halving that bin when the length is
+    even, as scipy does), synthesise `num` samples, scale by num / len(x).  x [Nx] -> [num]."""
+    x = np.asarray(x, dtype=np.float64)
+    Nx = len(x)
+    N = min(num, Nx)
+    K = N // 2
+    n = np.arange(Nx)
+    Y = np.array([np.sum(x * np.exp(-2j * np.pi * k * n / Nx)) for k in range(K + 1)])
+    if N % 2 == 0:
+        if num < Nx:
+            Y[K] *= 2.0
+        elif Nx < num:
+            Y[K] *= 0.5
+    m = np.arange(num)
+    y = np.full(num, Y[0].real)
+    for k in range(1, K + 1):
+        e = np.exp(2j * np.pi * k * m / num)
+        y += (Y[k] * e).real * (1.0 if 2 * k == num else 2.0)
+    return y / num * (num / Nx)
+
+
+def stretch_frames(audio, onsets, shifts, frame_length, pre_samples):
+    """StretchFrameExtractor.__call__ (data.py:207-223) for given shifts: -> [O, C, L] (or [O, L] for 1-D audio)."""
+    audio = np.asarray(audio)
+    onsets = np.asarray(onsets)
+    st = (onsets.min(axis=1) if audio.ndim == 2 else onsets) - pre_samples
+    out = np.empty(onsets.shape + (frame_length,), dtype=np.float32)
+    for i, (o, sh) in enumerate(zip(st, shifts)):
+        w = audio[o:o + frame_length + sh]
+        if audio.ndim == 2:
+            out[i] = np.stack([fourier_resample(w[:, c], frame_length) for c in range(audio.shape[1])])
+        else:
+            out[i] = fourier_resample(w, frame_length)
+    return out

@@ -121,3 +121,43 @@ def fix_onsets(audio, onsets, filter_size=5, d=0, onset_direction=None, take_abs
                 section_og[idx[0]] += ca
                 section_og[i] += cb
     return onsets
+
+
+def adjust_onset_rel(onsets, relx, rely, new_lag):
+    """detection.py:271-296."""
+    oa, ob = onsets[0], onsets[1]
+    lag_diff = (ob - oa) - new_lag
+    da = relx[oa + lag_diff] - relx[oa]
+    db = rely[ob - lag_diff] - rely[ob]
+    return (oa + lag_diff, ob) if da > db else (oa, ob - lag_diff)
+
+
+def filter_data(x, direction):
+    """detection.py:355-370 (returns a filtered COPY; the reference works in place)."""
+    x = np.array(x, copy=True)
+    diff = np.diff(x, 1, axis=0, prepend=x[:1])
+    if direction == "up":
+        x[diff < 0] = 0
+    elif direction == "down":
+        x[diff > 0] = 0
+    else:
+        raise RuntimeError(f"Unknown onset direction {direction=}!")
+    return x
+
+
+def detect_onset_region(audio, detected_onset, n=256, median_filter_size=5, threshold_factor=0.5):
+    """detection.py:454-484, spelled out without scipy: zero-padded running median, threshold, opening with a
+    centred 5-sample structure (erosion with the outside False, then dilation), first True (0 if none)."""
+    audio = np.asarray(audio)
+    start = max(detected_onset - n // 2, 0)
+    end = min(detected_onset + n // 2, len(audio))
+    a = np.abs(audio[start:end]).astype(np.float32)
+    h = median_filter_size // 2
+    pad = np.concatenate([np.zeros(h, np.float32), a, np.zeros(h, np.float32)])
+    f = np.array([np.sort(pad[i:i + median_filter_size])[h] for i in range(len(a))], np.float32)
+    b = f > np.float32(threshold_factor) * f.max()
+    bp = np.concatenate([np.zeros(2, bool), b, np.zeros(2, bool)])
+    er = np.array([bp[i:i + 5].all() for i in range(len(b))])
+    ep = np.concatenate([np.zeros(2, bool), er, np.zeros(2, bool)])
+    op = np.array([ep[i:i + 5].any() for i in range(len(b))])
+    return start + int(np.argmax(op))

@@ -90,6 +90,68 @@ def g18():
     save("g18_backtrack_py", **out)
 
 
+def g19():
+    """Per-onset callables next to the built rows: adjust_onset / adjust_onset_rel / filter_data /
+    detect_onset_region (detection.py:271-370, 454-484) and StretchFrameExtractor (data.py:195-223)."""
+    rng = np.random.default_rng(190)
+    out = {}
+    # adjust_onset: pairs of decaying bursts with known lags, onsets disturbed
+    n = 400
+    t = np.arange(120)
+    xs, ys, ons, lags, moves = [], [], [], [], []
+    for k in range(40):
+        x = (0.01 * rng.standard_normal(n)).astype(np.float32)
+        y = (0.01 * rng.standard_normal(n)).astype(np.float32)
+        ox, true_lag = int(rng.integers(120, 200)), int(rng.integers(-30, 40))
+        burst = (np.exp(-t / 25.0) * np.abs(np.sin(t / 3.0)) * (0.5 + rng.random())).astype(np.float32)
+        x[ox:ox + 120] += burst
+        y[ox + true_lag:ox + true_lag + 120] += burst * np.float32(0.8)
+        x, y = np.abs(x), np.abs(y)
+        o = [ox + int(rng.integers(-8, 9)), ox + true_lag + int(rng.integers(-8, 9))]
+        new_lag = true_lag + int(rng.integers(-2, 3))
+        if (o[1] - o[0]) - new_lag == 0:
+            new_lag += 1
+        try:
+            mv = det.adjust_onset(o, x, y, new_lag)
+        except ValueError:  # the reference's expression fails on an empty slice (x_end == x_start)
+            continue
+        xs.append(x), ys.append(y), ons.append(o), lags.append(new_lag), moves.append(mv)
+    out["adj_x"], out["adj_y"] = np.stack(xs), np.stack(ys)
+    out["adj_onsets"], out["adj_lag"], out["adj_moves"] = np.array(ons), np.array(lags), np.array(moves)
+    # adjust_onset_rel
+    relx, rely = np.abs(rng.standard_normal(300)).astype(np.float32), np.abs(rng.standard_normal(300)).astype(np.float32)
+    cases = [([100 + int(rng.integers(0, 50)), 160 + int(rng.integers(0, 50))], int(rng.integers(20, 90))) for _ in range(30)]
+    out["rel_x"], out["rel_y"] = relx, rely
+    out["rel_onsets"], out["rel_lag"] = np.array([c[0] for c in cases]), np.array([c[1] for c in cases])
+    out["rel_out"] = np.array([det.adjust_onset_rel(list(c[0]), relx, rely, c[1]) for c in cases])
+    # filter_data (in place in the reference)
+    xf = rng.standard_normal((500, 3)).astype(np.float32)
+    out["fil_x"] = xf.copy()
+    out["fil_up"] = det.filter_data(xf.copy(), "up")
+    out["fil_down"] = det.filter_data(xf.copy(), "down")
+    out["fil_1d_up"] = det.filter_data(xf[:, 0].copy(), "up")
+    # detect_onset_region
+    sig_ = synth.c1_sine_clicks(4.0, 48000, seed=19)[:, 0]
+    on = np.array([48000 + int(rng.integers(-40, 90)) + 24000 * k for k in range(6)] + [30, len(sig_) - 20, 60000])
+    out["reg_xsum"], out["reg_onsets"] = sig_.astype(np.float64).sum(), on  # (the audio is the seeded recipe)
+    for name, kw in (("a", {}), ("b", dict(n=512, median_filter_size=9, threshold_factor=0.3)),
+                     ("c", dict(n=100, median_filter_size=3, threshold_factor=0.7))):
+        out[f"reg_{name}"] = np.array([det.detect_onset_region(sig_, int(o), **kw) for o in on])
+    # StretchFrameExtractor under a numpy seed (shifts drawn with the reference's own calls)
+    data = ref.data
+    audio = synth.drum_hits(3, 1.0, 48000, seed=191, period=0.11)
+    onsets = np.array([[5000 + 5200 * k + 17 * c for c in range(3)] for k in range(7)])
+    for name, (L, pre, ms) in (("s1", (256, 16, 0.03)), ("s2", (200, 8, 0.05))):
+        np.random.seed(1900 + L)
+        out[f"str_{name}"] = data.StretchFrameExtractor(L, pre, ms)(audio, onsets)
+        np.random.seed(1900 + L)
+        out[f"str_{name}_1d"] = data.StretchFrameExtractor(L, pre, ms)(audio[:, 1].copy(), onsets[:, 1])
+    out["str_xsum"], out["str_onsets"] = audio.astype(np.float64).sum(), onsets
+    save("g19_postproc", **out)
+    print("g19:", len(moves), "adjust_onset pairs")
+
+
 if __name__ == "__main__":
     g17()
     g18()
+    g19()
