@@ -398,10 +398,10 @@ class StretchFrameExtractor(FrameExtractor):
         out = torch.empty((len(starts), C, self.frame_length), dtype=torch.float32, device=dev)
         if len(starts):
             xd = torch.from_numpy(a2).to(dev).contiguous()
-            check(_lib.lib().ofp_resample_windows(xd.data_ptr(), a2.shape[0], C, torch.from_numpy(starts).to(dev).data_ptr(),
-                                                  torch.from_numpy(nx).to(dev).data_ptr(), len(starts), int(nx.max()),
-                                                  self.frame_length, out.data_ptr(), _stream(dev)),
-                  "ofp_resample_windows")
+            st_d, nx_d = torch.from_numpy(starts).to(dev), torch.from_numpy(nx).to(dev)  # (kept alive across the launch)
+            check(_lib.lib().ofp_resample_windows(xd.data_ptr(), a2.shape[0], C, st_d.data_ptr(), nx_d.data_ptr(),
+                                                  len(starts), int(nx.max()), self.frame_length, out.data_ptr(),
+                                                  _stream(dev)), "ofp_resample_windows")
         res = out.cpu().numpy()
         return res if two_d else res[:, 0, :]
 
