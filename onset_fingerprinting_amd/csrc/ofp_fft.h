@@ -142,7 +142,10 @@ __device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
 template <int F>
 struct Cfg {
     static constexpr int M = F / 2;
-    static constexpr int T = (M / 8) < 16 ? 16 : (M / 8);   // lanes per frame
+    // lanes per frame: M/8 (one radix-8 butterfly per lane and pass), but never more than one wavefront up
+    // to 2048 points -- a 2048-point frame on 64 lanes (two butterflies per lane) synchronises its passes
+    // inside the wave instead of with workgroup barriers across two waves
+    static constexpr int T = (M / 8) < 16 ? 16 : ((M / 8) > 64 && F <= 2048 ? 64 : (M / 8));
     static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
     // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
