@@ -1,23 +1,38 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same
-# command, and the two PMC passes (counters only, separate runs) the roofline.traffic figure comes
-# from.  Everything lands in gpurun_out/prof_$1; copy what is to be judged into profiles/.
-set -e -o pipefail
+# Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command,
+# the two PMC passes (counters only, separate runs) behind roofline.traffic, the per-hop latencies of the
+# streaming session.  Everything lands in gpurun_out/prof_$1; copy what is to be judged into profiles/.
 TAG=${1:-vX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && cd $ROOT
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --inflight 1 --no-cpu > $O/bench_one_step_at_a_time.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py"
+timeout -k 10 400 $B > $O/bench.json 2> $O/bench.err || echo "bench FAILED"
+timeout -k 10 300 $B --clips 1 --inflight 1 --no-cpu --no-extras > $O/bench_one_clip_per_step.json 2>> $O/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/stats.err
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -1) $O/kernel_stats.csv
-python tools/trace_concurrency.py $O/stats 20 > $O/concurrency.txt
-# counters per launch do not depend on what else is in flight: one step at a time, with the tuning the default bench uses
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2, "mm_chunk": 8192}' > $O/pmc_f.json 2> $O/pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python bench.py --steps 2 --warmup 1 --no-cpu --inflight 1 --tuning '{"hp_span": 2, "mm_chunk": 8192}' > $O/pmc_w.json 2> $O/pmc_w.err
-cp $(ls $O/pmc_f/*/*counter_collection.csv | tail -1) $O/pmc_fetch_size.csv
-cp $(ls $O/pmc_w/*/*counter_collection.csv | tail -1) $O/pmc_write_size.csv
-python tools/pmc_traffic.py $O/pmc_fetch_size.csv $O/pmc_write_size.csv > $O/pmc_traffic_per_kernel.json
-rm -rf $O/stats $O/pmc_f $O/pmc_w
-head -c 600 $O/bench.json; echo; head -12 $O/kernel_stats.csv | cut -c1-150
+# counters per launch do not depend on what else is in flight: one step at a time
+for W in "c2x1 --clips 1" "c2x8 --clips 8"; do
+  set -- $W; name=$1; shift
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f_$name -- $B $@ --steps 2 --warmup 1 --no-cpu --no-extras --inflight 1 > $O/pmc_f_$name.json 2> $O/pmc_f_$name.err
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w_$name -- $B $@ --steps 2 --warmup 1 --no-cpu --no-extras --inflight 1 > $O/pmc_w_$name.json 2> $O/pmc_w_$name.err
+  cp $(ls $O/pmc_f_$name/*/*counter_collection.csv | tail -1) $O/pmc_fetch_size_$name.csv
+  cp $(ls $O/pmc_w_$name/*/*counter_collection.csv | tail -1) $O/pmc_write_size_$name.csv
+  python3 $ROOT/tools/pmc_traffic.py $O/pmc_fetch_size_$name.csv $O/pmc_write_size_$name.csv > $O/pmc_traffic_per_kernel_$name.json
+  rm -rf $O/pmc_f_$name $O/pmc_w_$name
+done
+rm -rf $O/stats
+timeout -k 10 120 python3 $ROOT/tools/stream_latency.py --config c5 --hops 10000 > $O/stream_latency_c5.json 2> $O/lat.err
+timeout -k 10 120 python3 $ROOT/tools/stream_latency.py --config realtime --hops 10000 > $O/stream_latency_realtime.json 2>> $O/lat.err
+OFP_HOP_GRAPH=nodes timeout -k 10 120 python3 $ROOT/tools/stream_latency.py --config c5 --hops 5000 > $O/stream_latency_c5_five_node_graph.json 2>> $O/lat.err
+head -c 900 $O/bench.json; echo; head -14 $O/kernel_stats.csv | cut -c1-150
+python3 - <<PY
+import json
+for n in ("c2x1", "c2x8"):
+    t = json.load(open("$O/pmc_traffic_per_kernel_%s.json" % n))
+    tot = sum(v["hbm_mb_per_launch"] * v["calls"] for v in t.values())
+    print(n, "PMC MB over the profiled run:", round(tot), {k: (v["calls"], round(v["hbm_mb_per_launch"])) for k, v in list(t.items())[:12]})
+for n in ("c5", "realtime", "c5_five_node_graph"):
+    j = json.load(open("$O/stream_latency_%s.json" % n)); print(n, j["p50_us"], j["p99_us"])
+PY
