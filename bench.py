@@ -113,6 +113,16 @@ def launch_ranks(n):
     return 0
 
 
+def usable_cpus():
+    """Worker processes this run may start: the CPUs it is allowed on, at most 16 (a GPU box hands one GPU's
+    job 16 of its cores whatever os.cpu_count() says; every worker also holds its own copy of a clip)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -169,9 +179,9 @@ def synth_batch(kind, idents, seconds, C, workers):
 
 
 def cpu_fanout(kind, seconds, sd):
-    """os.cpu_count() processes, one clip each (the process-per-core fan-out over clips)."""
+    """One process per usable core, one clip each (the process-per-core fan-out over clips)."""
     import multiprocessing as mp
-    n = os.cpu_count() or 1
+    n = usable_cpus()
     jobs = [(kind, 1000 + i, seconds, sd) for i in range(n)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(n) as pool:
@@ -266,7 +276,7 @@ def main():
         + 7919*clip.  c4: clip ids clip_lo.. from the recipe for slot 0; further slots (steps in flight) are
         distinct derived batches (channels rotated, gain changed) -- the host-side synthesis of another 512
         clips would take longer than the whole bench."""
-        workers = max(1, (os.cpu_count() or 1) // world)
+        workers = max(1, usable_cpus() // (world if world <= 2 else 1))
         if workload == "c2":
             xs = synth_batch("c2", [1 + rank + 97 * slot + 7919 * i for i in range(n_local)], seconds, C, workers)
         else:
@@ -505,7 +515,7 @@ def main():
             mel_err = float((np.abs(gm - cb["mel"]) / cb["mel"]).max())
             gl = out["logits"][0, :, :Hs].cpu().numpy()
             log_err = float(np.abs(gl - cb["logits"]).max() / np.abs(cb["logits"]).max())
-            fan = cpu_fanout(workload, secs, sd)
+            fan = cpu_fanout(workload, min(secs, 20.0), sd)  # (bounded: every worker holds its clip's fp64 spectra)
             result["cpu_baseline"] = {"value": cb["frames"] / cb["seconds"], "unit": "frames/s", "cores": 1, "kind": "port",
                                       "cpu_model": cpu_model(),
                                       "sample": f"the first {secs:.0f} s of clip 0 of the timed batch ({cb['frames']} frames) "
