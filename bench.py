@@ -14,9 +14,9 @@ Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the
 `--gpus` must then equal WORLD_SIZE (anything else is refused, loudly).
 
 Workloads (BASELINE.json configs):
-  c2  (default at N = 1)  `--clips` (default 8) DISTINCT 8-channel 60 s clips per GPU and step
+  c2  (default at N = 1)  `--clips` (default 16) DISTINCT 8-channel 60 s clips per GPU and step
       (configs[1], the configuration the metric is quoted on, as a batch: one library call processes
-      the clips side by side -- 64 chains).  Every rank owns its own clips: scaling "weak".
+      the clips side by side -- 128 chains).  Every rank owns its own clips: scaling "weak".
       `config.one_clip_per_step` is the same path on ONE clip per step (8 chains, latency-bound).
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
       (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
@@ -199,13 +199,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c2", "c4"], default=None)
-    ap.add_argument("--clips", type=int, default=8, help="c2: distinct clips per GPU and step")
+    ap.add_argument("--clips", type=int, default=16, help="c2: distinct clips per GPU and step")
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra figures (one clip per step, whole batch)")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
     ap.add_argument("--rehearsal", action="store_true", help="control flow only, no GPU work (CPU tests)")
+    ap.add_argument("--shard-of", type=int, default=0, help="c4 on ONE GPU: process only rank 0's shard of a world of this "
+                    "size (what one rank of an N-GPU run does per step, without the exchange partners); the line is "
+                    "marked as such and its value counts this shard's frames only")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -251,8 +254,8 @@ def main():
         scaling = "weak"
     else:
         C, seconds = C4["C"], C4["seconds"]
-        clip_lo, clip_hi = shard_range(C4["clips"], rank, world)
-        n_local, total_clips = clip_hi - clip_lo, C4["clips"]
+        clip_lo, clip_hi = shard_range(C4["clips"], rank, args.shard_of if (world == 1 and args.shard_of > 1) else world)
+        n_local, total_clips = clip_hi - clip_lo, (C4["clips"] if not (world == 1 and args.shard_of > 1) else clip_hi - clip_lo)
         scaling = "strong"
     N = int(seconds * SR)
     H = synth.n_frames(N, NFFT, HOP)
@@ -468,6 +471,9 @@ def main():
         else:
             wl = (f"C4: 512 clips x 4 ch x 10 s @ 48 kHz (Poisson hits) sharded {n_local} clips per GPU, 1024/256, "
                   "detect + rFFT |X|^2 + 40-mel + FCNN(40-10-10-10-8); RCCL all-gather of the onset records")
+            if world == 1 and args.shard_of > 1:
+                wl = (f"ONE RANK'S SHARE of C4 over {args.shard_of} GPUs ({n_local} of the 512 clips x 4 ch x 10 s), measured "
+                      "alone on one GPU: value counts this shard only")
         result = {
             "metric": "frames/sec (1024-pt, hop 256, 48 kHz) detect+FFT+classify at 1/2/4/8 MI355X",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
