@@ -333,6 +333,18 @@ typedef struct ofp_hop_config {
     int32_t fb_nnz;
     const ofp_mlp* mlp;     /* classifier on the n_mels bands, or NULL; parameters are copied */
     int32_t want_rel;       /* != 0: the hop's relative envelope [B][C] is copied back too */
+    /* Per-hop onset strength of the channel mean (realtime/recording.py:273-311, RecAnalysis.fft +
+     * onset_strength): symmetric float32 Hann x audio[-n_fft:].mean(-1), rFFT, dB floored 80 dB below a tracked
+     * maximum, positive flux against the previous frame averaged over the bins, normalised by a tracked
+     * min / max, moving max / mean over the last max_length / avg_length entries (the reference reads these
+     * two from config.MAX_LENGTH / AVG_LENGTH, which its config.py does not define).  The trackers are
+     * loopmate.EMA_MinMaxTracker objects (:251-256); loopmate is absent, their update is ASSUMED to be
+     * envelope_follower.c:27-57 with a single alpha: PARITY UNPINNED. */
+    int32_t strength;       /* != 0: enabled */
+    int32_t strength_ring;  /* entries of the onset-envelope ring (the reference's n_stft) */
+    int32_t max_length, avg_length;
+    float ls_max0, ls_minmax, ls_alpha;            /* EMA_MinMaxTracker(max0=10, minmax=0, alpha=0.0005) */
+    float oe_min0, oe_minmin, oe_max0, oe_alpha;   /* EMA_MinMaxTracker(min0=0, minmin=0, max0=1, alpha=0.001) */
 } ofp_hop_config;
 typedef struct ofp_hop_session ofp_hop_session; /* opaque */
 int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session** out);
@@ -343,12 +355,13 @@ int ofp_hop_reset(ofp_hop_session* s);
 int ofp_hop_warmup(ofp_hop_session* s, const float* h_x, int64_t n_rows);
 /* One hop, h_hop [B][C].  Outputs (each may be NULL): *n_onsets; h_records [C] with .sample =
  * hop_index * B + delta (audio.py:65) and .clip = 0, in channel order; h_logits [C][mlp outputs];
- * h_mel [C][n_mels]; h_rel [B][C] (needs want_rel). */
+ * h_mel [C][n_mels]; h_rel [B][C] (needs want_rel); h_strength [4] = {flux, normalised, moving max, moving mean}
+ * (needs strength). */
 int ofp_hop_submit(ofp_hop_session* s, const float* h_hop);
 int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records, float* h_logits, float* h_mel,
-                    float* h_rel);
+                    float* h_rel, float* h_strength);
 int ofp_hop_push(ofp_hop_session* s, const float* h_hop, int64_t* n_onsets, ofp_onset* h_records, float* h_logits,
-                 float* h_mel, float* h_rel);
+                 float* h_mel, float* h_rel, float* h_strength);
 /* audio[-n_rows:] of the ring buffer (oldest row first), h_out [n_rows][C]; n_rows <= ring_samples */
 int ofp_hop_ring_read(ofp_hop_session* s, int64_t n_rows, float* h_out);
 

@@ -72,6 +72,13 @@ class HopConfig(ctypes.Structure):
         ("fb_nnz", ctypes.c_int32),
         ("mlp", ctypes.c_void_p),
         ("want_rel", ctypes.c_int32),
+        ("strength", ctypes.c_int32),
+        ("strength_ring", ctypes.c_int32),
+        ("max_length", ctypes.c_int32),
+        ("avg_length", ctypes.c_int32),
+        ("ls_max0", ctypes.c_float), ("ls_minmax", ctypes.c_float), ("ls_alpha", ctypes.c_float),
+        ("oe_min0", ctypes.c_float), ("oe_minmin", ctypes.c_float), ("oe_max0", ctypes.c_float),
+        ("oe_alpha", ctypes.c_float),
     ]
 
 
@@ -132,8 +139,8 @@ SIGNATURES = {
     "ofp_hop_reset": (ctypes.c_int, [_vp]),
     "ofp_hop_warmup": (ctypes.c_int, [_vp, _vp, _i64]),
     "ofp_hop_submit": (ctypes.c_int, [_vp, _vp]),
-    "ofp_hop_collect": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
-    "ofp_hop_push": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp]),
+    "ofp_hop_collect": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
+    "ofp_hop_push": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i64), _vp, _vp, _vp, _vp, _vp]),
     "ofp_hop_ring_read": (ctypes.c_int, [_vp, _i64, _vp]),
     "ofp_autocorr_softmax": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ofp_conv1d": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp,

@@ -15,8 +15,10 @@ namespace ofpfft {
 
 using ofp::cdiv;
 
+// complex product with explicit fused multiply-adds: 4 instructions instead of 6 (the library is built with
+// -ffp-contract=off for the detector's arithmetic canon, so the FMA is spelled out where it is wanted)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -187,6 +189,80 @@ __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, i
     float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
     float2 t = cmul(twF[k], o);
     return cadd(e, mul_mi(t));
+}
+
+// |X[p]|^2 and |X[M-p]|^2 of the real FFT from ONE pair (Z[p], Z[M-p]) of the packed transform: with
+// e = (Z[p] + conj Z[M-p]) / 2, o = (Z[p] - conj Z[M-p]) / 2, t = W_F^p o:  X[p] = e - i t,  X[M-p] = conj(e + i t)
+// -- half the loads, twiddles and products of evaluating the two bins separately.  p in [0, M/2]; for
+// p = M/2 the two bins coincide (pb is then that bin again).
+template <int M>
+__device__ __forceinline__ void rfft_power_pair(const float2* Z, const float2* twF, int p, float& pa, float& pb) {
+    const float2 zk = Z[p & (M - 1)];
+    float2 zm = Z[(M - p) & (M - 1)];
+    zm.y = -zm.y;
+    const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+    const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
+    const float2 t = cmul(twF[p], o);
+    const float ar = e.x + t.y, ai = e.y - t.x;   // X[p]
+    const float br = e.x - t.y, bi = e.y + t.x;   // conj X[M-p]
+    pa = fmaf(ar, ar, ai * ai);
+    pb = fmaf(br, br, bi * bi);
+}
+
+// ---- mel band sums of one frame's power spectrum (LDS), shared by k_mel, the epilogue of k_stft_power and
+// the per-hop kernel so that all three give the same bits.  A band's sum is DEFINED as the sum, in order, of
+// its 32-tap segments, each segment a chain acc = fma(p[k], w[k], acc) from 0: the segments of all bands are
+// spread over the lanes of the frame (a wide top band no longer makes one lane walk 64-256 taps while the
+// others idle), then lane b adds the segments of band b.
+constexpr int MEL_SEG = 32;
+constexpr int MEL_MAXSEG = 256;
+
+struct MelSegs {            // in LDS, built once per workgroup
+    unsigned short first[128];   // first segment of band b (n_mels <= 127), first[n_mels] = total
+    unsigned char band[MEL_MAXSEG];
+    unsigned char part[MEL_MAXSEG];
+};
+
+// single thread (or all threads redundantly writing the same values): fills the segment table
+__device__ __forceinline__ void mel_build_segs(MelSegs* ms, const int32_t* flen, int n_mels) {
+    int s = 0;
+    for (int b = 0; b < n_mels; ++b) {
+        ms->first[b] = (unsigned short)s;
+        const int n = (flen[b] + MEL_SEG - 1) / MEL_SEG;
+        for (int q = 0; q < n && s < MEL_MAXSEG; ++q, ++s) {
+            ms->band[s] = (unsigned char)b;
+            ms->part[s] = (unsigned char)q;
+        }
+    }
+    ms->first[n_mels] = (unsigned short)s;
+}
+
+__device__ __forceinline__ float mel_segment(const float* pf, const float* fw, const int32_t* flo, const int32_t* flen,
+                                             const int32_t* foff, int b, int q) {
+    const int k0 = q * MEL_SEG, k1 = min(flen[b], k0 + MEL_SEG);
+    const float* p = pf + flo[b];
+    const float* wb = fw + foff[b];
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc = fmaf(p[k], wb[k], acc);
+    return acc;
+}
+
+// the T lanes of a frame (tid in [0, T)); partial: MEL_MAXSEG floats of LDS owned by this frame; SYNC() makes the
+// partial sums visible to the frame's lanes
+template <class Sync, class Store>
+__device__ __forceinline__ void mel_bands(const MelSegs* ms, const float* pf, const float* fw, const int32_t* flo,
+                                          const int32_t* flen, const int32_t* foff, int n_mels, int tid, int T,
+                                          float* partial, Sync&& sync, Store&& store) {
+    const int n_segs = ms->first[n_mels];
+    for (int s = tid; s < n_segs; s += T) partial[s] = mel_segment(pf, fw, flo, flen, foff, ms->band[s], ms->part[s]);
+    sync();
+    for (int b = tid; b < n_mels; b += T) {
+        const int s0 = ms->first[b], s1 = ms->first[b + 1];
+        float acc = s1 > s0 ? partial[s0] : 0.0f;
+        for (int s = s0 + 1; s < s1; ++s) acc += partial[s];
+        store(b, acc);
+    }
 }
 
 }  // namespace ofpfft

@@ -36,7 +36,24 @@ using namespace ofpfft;
 
 namespace {
 
+// Per-hop onset strength of the channel mean (realtime/recording.py:273-311, RecAnalysis.fft +
+// onset_strength): symmetric float32 Hann x mean over channels of audio[-n_fft:], rFFT, |X|^2 in dB floored 80 dB
+// below a tracked maximum, positive flux against the previous frame averaged over the bins, normalised by a
+// tracked min / max, moving max / mean over the last frames.  The two trackers are loopmate.EMA_MinMaxTracker
+// objects -- loopmate is not available, their arithmetic is ASSUMED to be that of envelope_follower.c:27-57
+// with one alpha (PARITY UNPINNED).
+struct StrengthArgs {
+    int enabled, n_ring, max_length, avg_length;
+    float ls_alpha, ls_minmax, oe_alpha, oe_minmin;
+    const float* wsym;  // [F] scipy.signal.windows.hann(F) as float32
+    float* prev;        // [F/2+1] power spectrum of the previous hop's frame
+    float* st;          // [4] ls_max, oe_min, oe_max
+    float* ring;        // [n_ring] normalised onset envelope, one entry per hop
+    float* out;         // [4] raw flux, normalised, moving max, moving mean (result block)
+};
+
 struct HopArgs {
+    StrengthArgs sg;
     int C, B, n_mels, nnz, mean_mode;
     int64_t R;             // rows of the ring buffer
     int64_t* ctl;          // [0] hops pushed so far (incremented by k_hop_begin), [1] spare
@@ -66,8 +83,10 @@ __global__ void k_hop_begin(HopArgs a) {
 }
 
 template <int F>
-__global__ void k_hop_tables(float2* twM, float2* twF, float* win) {
+__global__ void k_hop_tables(float2* twM, float2* twF, float* win, float* wsym) {
     build_tables<F>(twM, twF, win, F);
+    for (int n = threadIdx.x; n < F; n += blockDim.x)  // symmetric Hann (recording.py:249), fp64 then float32
+        wsym[n] = (float)(0.5 - 0.5 * cospi(2.0 * (double)n / (double)(F - 1)));
 }
 
 template <int F>
@@ -92,7 +111,9 @@ __device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64
     int32_t* flo = reinterpret_cast<int32_t*>(fw + a.nnz);
     int32_t* flen = flo + a.n_mels;
     int32_t* foff = flen + a.n_mels;
-    float* mprm = reinterpret_cast<float*>(foff + a.n_mels);
+    MelSegs* segs = reinterpret_cast<MelSegs*>((reinterpret_cast<uintptr_t>(foff + a.n_mels) + 15) & ~(uintptr_t)15);
+    float* partial = reinterpret_cast<float*>(segs + 1);
+    float* mprm = partial + MEL_MAXSEG;
     float* tileA = mprm + ((a.plan.n_params + 3) & ~3);
     float* tileB = tileA + 16 * a.plan.st_a;
     float* hcol = tileB + 16 * a.plan.st_b;  // [B] this channel's column of the hop
@@ -113,6 +134,7 @@ __device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64
     for (int i = tid; i < a.plan.n_params; i += WGS) mprm[i] = a.plan.params[i];
     if (a.plan.n_layers > 0)
         for (int i = tid; i < 16 * a.plan.st_a; i += WGS) tileA[i] = 0.0f;
+    if (tid == 0) mel_build_segs(segs, a.flen, a.n_mels);
     const int64_t first = (h - 1) * B;  // stream index of this hop's first sample
     __syncthreads();
     // ring-buffer write of this channel's column (realtime/audio.py:97)
@@ -128,35 +150,33 @@ __device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64
     for (int p = tid; p < M; p += WGS)
         A[p] = make_float2(sample(base + 2 * p) * win[2 * p], sample(base + 2 * p + 1) * win[2 * p + 1]);
     __syncthreads();
-    constexpr int NK = M / T + 1;
-    float pk[NK];
     if (tid < T) {
         cfft<M, T>(A, twM, tid);
+        // the same paired power bins, LDS staging and band sums as k_stft_power (bit-identical to its frame)
+        constexpr int NQ = (M / 2) / T + 1;
+        float pa[NQ], pb[NQ];
 #pragma unroll
-        for (int q = 0; q < NK; ++q) {
-            const int k = tid + q * T;
-            pk[q] = 0.0f;
-            if (k <= M) {
-                const float2 X = rfft_bin<M>(A, twF, k);
-                pk[q] = X.x * X.x + X.y * X.y;
-            }
+        for (int q = 0; q < NQ; ++q) {
+            const int pp = tid + q * T;
+            pa[q] = pb[q] = 0.0f;
+            if (pp <= M / 2) rfft_power_pair<M>(A, twF, pp, pa[q], pb[q]);
         }
         frame_sync<T>();  // every bin of the spectrum has been read
         float* pf = reinterpret_cast<float*>(A);
 #pragma unroll
-        for (int q = 0; q < NK; ++q)
-            if (tid + q * T <= M) pf[tid + q * T] = pk[q];
-        frame_sync<T>();
-        for (int b = tid; b < a.n_mels; b += T) {  // same summation order as k_mel / k_stft_power
-            const float* p = pf + flo[b];
-            const float* wb = fw + foff[b];
-            float acc = 0.0f;
-            const int nb_ = flen[b];
-#pragma unroll 4
-            for (int k = 0; k < nb_; ++k) acc = fmaf(p[k], wb[k], acc);
-            a.mel[c * a.n_mels + b] = acc;
-            if (a.plan.n_layers > 0) tileA[b] = acc;  // row 0 of the classifier's tile
+        for (int q = 0; q < NQ; ++q) {
+            const int pp = tid + q * T;
+            if (pp <= M / 2) {
+                pf[pp] = pa[q];
+                if (pp < M / 2) pf[M - pp] = pb[q];
+            }
         }
+        frame_sync<T>();
+        mel_bands(segs, pf, fw, flo, flen, foff, a.n_mels, tid, T, partial, [] { frame_sync<T>(); },
+                  [&](int b, float acc) {
+                      a.mel[c * a.n_mels + b] = acc;
+                      if (a.plan.n_layers > 0) tileA[b] = acc;  // row 0 of the classifier's tile
+                  });
     }
     if (a.plan.n_layers > 0) {
         __syncthreads();
@@ -167,6 +187,138 @@ __device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64
             });
         }
     }
+}
+
+// One workgroup: the channel-mean frame of the hop that ends at sample h*B and its onset strength.
+template <int F, int WGS>
+__device__ __forceinline__ void hop_strength_body(const HopArgs& a, int64_t h, unsigned char* smem) {
+    constexpr int M = HopCfg<F>::M, T = HopCfg<F>::T;
+    static_assert(T <= 64 ? WGS >= 64 : WGS == T, "lanes of a multi-wave frame must be the whole workgroup");
+    const StrengthArgs& g = a.sg;
+    float2* twM = reinterpret_cast<float2*>(smem);
+    float2* twF = twM + M;
+    float2* A = twF + M + 2;
+    float* hbuf = reinterpret_cast<float*>(A + M);   // [B][C] the hop
+    float* red = hbuf + (size_t)a.B * a.C;            // [WGS / 64 + 2]
+    const int C = a.C, B = a.B, tid = threadIdx.x;
+    for (int k = tid; k < M; k += WGS) twM[k] = a.twM[k];
+    for (int k = tid; k <= M; k += WGS) twF[k] = a.twF[k];
+    for (int i = tid; i < B * C; i += WGS) hbuf[i] = a.hop[i];
+    __syncthreads();
+    const int64_t first = (h - 1) * B, base = h * B - F;
+    auto mean_sample = [&](int64_t s) -> float {  // audio[-n_fft:].mean(-1): float32 sum in channel order, then / C
+        if (s < 0) return 0.0f;
+        float m = 0.0f;
+        if (s >= first) {
+            for (int c = 0; c < C; ++c) m += hbuf[(s - first) * C + c];
+        } else {
+            const float* r = a.ring + (s % a.R) * C;
+            for (int c = 0; c < C; ++c) m += r[c];
+        }
+        return m / (float)C;
+    };
+    for (int p = tid; p < M; p += WGS)
+        A[p] = make_float2(g.wsym[2 * p] * mean_sample(base + 2 * p), g.wsym[2 * p + 1] * mean_sample(base + 2 * p + 1));
+    __syncthreads();
+    constexpr int NK = M / T + 1;
+    float pw[NK], sdb[NK];
+    float smax = -INFINITY;
+    if (tid < T) {
+        cfft<M, T>(A, twM, tid);
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = tid + q * T;
+            pw[q] = 0.0f;
+            sdb[q] = -INFINITY;
+            if (k <= M) {
+                const float2 X = rfft_bin<M>(A, twF, k);
+                pw[q] = X.x * X.x + X.y * X.y;
+                sdb[q] = 10.0f * log10f(fmaxf(1e-10f, pw[q]));   // :290
+                smax = fmaxf(smax, sdb[q]);
+            }
+        }
+    }
+    // block maximum of the dB spectrum -> the tracked maximum (:291), floor 80 dB below it (:292-294)
+    for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o));
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = red[0];
+        for (int w = 1; w < (WGS + 63) / 64; ++w) m = fmaxf(m, red[w]);
+        float ls = g.st[0];
+        ls = m > ls ? m : (1.0f - g.ls_alpha) * ls + g.ls_alpha * m;
+        ls = fmaxf(ls, g.ls_minmax);
+        g.st[0] = ls;
+        red[WGS / 64 + 1] = ls - 80.0f;
+    }
+    __syncthreads();
+    const float floor_db = red[WGS / 64 + 1];
+    float fsum = 0.0f;
+    if (tid < T) {
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = tid + q * T;
+            if (k <= M) {
+                const float s1 = fmaxf(sdb[q], floor_db);
+                const float s0 = fmaxf(10.0f * log10f(fmaxf(1e-10f, g.prev[k])), floor_db);
+                fsum += fmaxf(0.0f, s1 - s0);                       // :296
+                g.prev[k] = pw[q];
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) fsum += __shfl_xor(fsum, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = fsum;
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.0f;
+        for (int w = 0; w < (WGS + 63) / 64; ++w) sum += red[w];
+        const float oe = sum / (float)(M + 1);
+        float mn = g.st[1], mx = g.st[2];
+        mx = oe > mx ? oe : (1.0f - g.oe_alpha) * mx + g.oe_alpha * oe;   // :299 add_sample
+        mn = oe < mn ? oe : (1.0f - g.oe_alpha) * mn + g.oe_alpha * oe;
+        mn = fmaxf(mn, g.oe_minmin);
+        g.st[1] = mn;
+        g.st[2] = mx;
+        const float norm = (oe - mn) / (mx - mn);                          // :300-302 normalize_sample
+        g.ring[(h - 1) % g.n_ring] = norm;
+        g.out[0] = oe;
+        g.out[1] = norm;
+    }
+    __syncthreads();
+    // moving max / mean over the last MAX_LENGTH / AVG_LENGTH entries (:304-311; entries before the stream
+    // started are the zeros the ring was created with)
+    float vmax = -INFINITY, vsum = 0.0f;
+    for (int i = tid; i < max(g.max_length, g.avg_length); i += WGS) {
+        const int64_t e = h - 1 - i;
+        const float v = e >= 0 ? g.ring[e % g.n_ring] : 0.0f;
+        if (i < g.max_length) vmax = fmaxf(vmax, v);
+        if (i < g.avg_length) vsum += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        vsum += __shfl_xor(vsum, o);
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = vmax;
+        hbuf[tid >> 6] = vsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float m = red[0], sm = hbuf[0];
+        for (int w = 1; w < (WGS + 63) / 64; ++w) {
+            m = fmaxf(m, red[w]);
+            sm += hbuf[w];
+        }
+        g.out[2] = m;
+        g.out[3] = sm / (float)g.avg_length;
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(HopCfg<F>::WGS) void k_hop_strength(HopArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    hop_strength_body<F, HopCfg<F>::WGS>(a, a.ctl[0], smem);
 }
 
 template <int F>
@@ -192,8 +344,10 @@ __global__ __launch_bounds__(FusedCfg<F>::WGS) void k_hop_fused(HopArgs a, ofpst
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) *a.hop_index = done;
         ofpstream::stream_par_blocks(sa, reinterpret_cast<float*>(smem));
-    } else {
+    } else if ((int)blockIdx.x <= a.C) {
         hop_spectral_body<F, FusedCfg<F>::WGS>(a, (int)blockIdx.x - 1, done + 1, smem);
+    } else {  // the onset-strength workgroup (only launched when enabled)
+        hop_strength_body<F, FusedCfg<F>::WGS>(a, done + 1, smem);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -224,6 +378,11 @@ struct ofp_hop_session {
     float2* d_twM = nullptr;
     float2* d_twF = nullptr;
     float* d_win = nullptr;
+    float* d_wsym = nullptr;
+    float* d_sg = nullptr;      // onset strength: prev power [bins] | st [4] | ring [n_ring]
+    float sg_init[4] = {10.0f, 0.0f, 1.0f, 0.0f};  // ls_max0, oe_min0, oe_max0
+    size_t sg_floats = 0;
+    size_t lds_strength = 0;
     int32_t* d_fb_i = nullptr;  // lo | len | off
     float* d_fb_w = nullptr;
     float* d_prm = nullptr;     // own copy of the classifier's parameters
@@ -231,7 +390,7 @@ struct ofp_hop_session {
     float* h_hop = nullptr;           // pinned
     unsigned char* h_res = nullptr;   // pinned
     // result block layout (bytes)
-    int64_t o_count = 0, o_index = 8, o_done = 16, o_rec = 24, o_logits = 0, o_mel = 0, o_rel = 0, res_bytes = 0;
+    int64_t o_count = 0, o_index = 8, o_done = 16, o_rec = 24, o_logits = 0, o_mel = 0, o_rel = 0, o_sg = 0, res_bytes = 0;
     HopArgs args;
     ofpstream::StreamArgs sargs;  // fused form: the detector workgroup's arguments
     bool fused = false;
@@ -245,7 +404,7 @@ namespace {
 
 template <int F>
 int hop_tables(ofp_hop_session* s) {
-    hipLaunchKernelGGL(k_hop_tables<F>, dim3(1), dim3(256), 0, s->stream, s->d_twM, s->d_twF, s->d_win);
+    hipLaunchKernelGGL(k_hop_tables<F>, dim3(1), dim3(256), 0, s->stream, s->d_twM, s->d_twF, s->d_win, s->d_wsym);
     OFP_LAUNCH_CHECK("k_hop_tables");
     return OFP_OK;
 }
@@ -261,11 +420,32 @@ int hop_spectral(ofp_hop_session* s) {
 }
 
 template <int F>
+int hop_strength(ofp_hop_session* s) {
+    if (s->lds_strength > 65536)
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hop_strength<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_strength));
+    hipLaunchKernelGGL(k_hop_strength<F>, dim3(1), dim3(HopCfg<F>::WGS), s->lds_strength, s->stream, s->args);
+    OFP_LAUNCH_CHECK("k_hop_strength");
+    return OFP_OK;
+}
+
+int dispatch_strength(ofp_hop_session* s) {
+    switch (s->n_fft) {
+        case 256: return hop_strength<256>(s);
+        case 512: return hop_strength<512>(s);
+        case 1024: return hop_strength<1024>(s);
+        case 2048: return hop_strength<2048>(s);
+        case 4096: return hop_strength<4096>(s);
+    }
+    return ofp::fail(OFP_ERR_INVALID, "n_fft %d not supported (256,512,1024,2048,4096)", s->n_fft);
+}
+
+template <int F>
 int hop_fused(ofp_hop_session* s) {
     if (s->lds_fused > 65536 - 20480)  // (the detector's static LDS comes on top)
         OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hop_fused<F>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_fused));
-    hipLaunchKernelGGL(k_hop_fused<F>, dim3((unsigned)s->C + 1), dim3(FusedCfg<F>::WGS), s->lds_fused, s->stream, s->args,
+    hipLaunchKernelGGL(k_hop_fused<F>, dim3((unsigned)s->C + 1 + (s->args.sg.enabled ? 1 : 0)), dim3(FusedCfg<F>::WGS), s->lds_fused, s->stream, s->args,
                        s->sargs);
     OFP_LAUNCH_CHECK("k_hop_fused");
     return OFP_OK;
@@ -323,6 +503,11 @@ int enqueue_hop(ofp_hop_session* s) {
                                 reinterpret_cast<ofp_onset*>(s->d_res + s->o_rec), s->C,
                                 reinterpret_cast<int64_t*>(s->d_res + s->o_count), s->stream);
     if (rc != OFP_OK) return rc;
+    if (s->args.sg.enabled) {  // (before the spectral node: it reads ring rows the spectral node is about to overwrite
+                               //  only for hops older than the ring, never the current one)
+        rc = dispatch_strength(s);
+        if (rc != OFP_OK) return rc;
+    }
     rc = dispatch_spectral(s);
     if (rc != OFP_OK) return rc;
     OFP_HIP(hipMemcpyAsync(s->h_res, s->d_res, (size_t)s->res_bytes, hipMemcpyDeviceToHost, s->stream));
@@ -335,6 +520,10 @@ int reset_state(ofp_hop_session* s) {
     OFP_HIP(hipMemsetAsync(s->d_ring, 0, (size_t)s->R * s->C * sizeof(float), s->stream));
     OFP_HIP(hipMemsetAsync(s->d_ctl, 0, 2 * sizeof(int64_t), s->stream));
     OFP_HIP(hipMemsetAsync(s->d_res, 0, (size_t)s->res_bytes, s->stream));
+    if (s->d_sg) {
+        OFP_HIP(hipMemsetAsync(s->d_sg, 0, s->sg_floats * 4, s->stream));
+        OFP_HIP(hipMemcpyAsync(s->args.sg.st, s->sg_init, 16, hipMemcpyHostToDevice, s->stream));
+    }
     OFP_HIP(hipStreamSynchronize(s->stream));
     std::memset(s->h_res, 0, (size_t)s->res_bytes);
     s->pushed = 0;
@@ -351,7 +540,7 @@ int ofp_hop_destroy(ofp_hop_session* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->exec) (void)hipGraphExecDestroy(s->exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
-    void* dev[] = {s->d_state, s->d_hop, s->d_ring, s->d_ctl, s->d_twM, s->d_twF, s->d_win, s->d_fb_i, s->d_fb_w,
+    void* dev[] = {s->d_state, s->d_hop, s->d_ring, s->d_ctl, s->d_twM, s->d_twF, s->d_win, s->d_wsym, s->d_sg, s->d_fb_i, s->d_fb_w,
                    s->d_prm, s->d_res};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -375,6 +564,8 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
                 "ofp_hop_create: NULL / empty filterbank");
     OFP_REQUIRE(cfg->fb_nnz <= 4 * (cfg->n_fft / 2 + 1), "ofp_hop_create: filterbank with %d weights for %d bins",
                 cfg->fb_nnz, cfg->n_fft / 2 + 1);
+    OFP_REQUIRE(cfg->n_mels <= 127 && cfg->fb_nnz / MEL_SEG + cfg->n_mels <= MEL_MAXSEG,
+                "ofp_hop_create: at most 127 bands and %d 32-tap segments", MEL_MAXSEG);
     OFP_REQUIRE(!cfg->mlp || cfg->mlp->plan.dims[0] == cfg->n_mels,
                 "ofp_hop_create: the classifier takes %d inputs, the filterbank has %d bands",
                 cfg->mlp ? cfg->mlp->plan.dims[0] : 0, cfg->n_mels);
@@ -395,11 +586,12 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     s->o_logits = up8(s->o_rec + (int64_t)C * (int64_t)sizeof(ofp_onset));
     s->o_mel = up8(s->o_logits + (int64_t)C * s->n_out * 4);
     s->o_rel = up8(s->o_mel + (int64_t)C * s->n_mels * 4);
-    s->res_bytes = up8(s->o_rel + (s->want_rel ? (int64_t)B * C * 4 : 0));
+    s->o_sg = up8(s->o_rel + (s->want_rel ? (int64_t)B * C * 4 : 0));
+    s->res_bytes = up8(s->o_sg + 16);
     const int M = s->n_fft / 2;
     const int st_a = cfg->mlp ? plan.st_a : 0, st_b = cfg->mlp ? plan.st_b : 0;
     s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)M * 8 + (size_t)cfg->fb_nnz * 4 +
-             (size_t)3 * s->n_mels * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + (size_t)B * 4 + 64;
+             (size_t)3 * s->n_mels * 4 + 16 + sizeof(MelSegs) + (size_t)MEL_MAXSEG * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + (size_t)B * 4 + 64;
     int rc = OFP_OK;
     auto fail = [&](int code) {
         ofp_hop_destroy(s);
@@ -426,6 +618,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     HOP_TRY(hipMalloc(&s->d_twM, (size_t)M * 8));
     HOP_TRY(hipMalloc(&s->d_twF, (size_t)(M + 2) * 8));
     HOP_TRY(hipMalloc(&s->d_win, (size_t)s->n_fft * 4));
+    HOP_TRY(hipMalloc(&s->d_wsym, (size_t)s->n_fft * 4));
     HOP_TRY(hipMalloc(&s->d_fb_i, (size_t)3 * s->n_mels * 4));
     HOP_TRY(hipMalloc(&s->d_fb_w, (size_t)cfg->fb_nnz * 4));
     HOP_TRY(hipMalloc(&s->d_res, (size_t)s->res_bytes));
@@ -464,6 +657,33 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     a.mel = reinterpret_cast<float*>(s->d_res + s->o_mel);
     a.count = reinterpret_cast<int64_t*>(s->d_res + s->o_count);
     a.hop_index = reinterpret_cast<int64_t*>(s->d_res + s->o_index);
+    if (cfg->strength) {
+        OFP_REQUIRE(cfg->strength_ring >= 1 && cfg->max_length >= 1 && cfg->avg_length >= 1 &&
+                        cfg->max_length <= cfg->strength_ring && cfg->avg_length <= cfg->strength_ring,
+                    "ofp_hop_create: onset strength needs 1 <= max_length, avg_length <= strength_ring");
+        const int bins = s->n_fft / 2 + 1;
+        s->sg_floats = (size_t)bins + 4 + (size_t)cfg->strength_ring;
+        HOP_TRY(hipMalloc(&s->d_sg, s->sg_floats * 4));
+        StrengthArgs& g = a.sg;
+        g.enabled = 1;
+        g.n_ring = cfg->strength_ring;
+        g.max_length = cfg->max_length;
+        g.avg_length = cfg->avg_length;
+        g.ls_alpha = cfg->ls_alpha;
+        g.ls_minmax = cfg->ls_minmax;
+        g.oe_alpha = cfg->oe_alpha;
+        g.oe_minmin = cfg->oe_minmin;
+        g.wsym = s->d_wsym;
+        g.prev = s->d_sg;
+        g.st = s->d_sg + bins;
+        g.ring = s->d_sg + bins + 4;
+        g.out = reinterpret_cast<float*>(s->d_res + s->o_sg);
+        s->sg_init[0] = cfg->ls_max0;
+        s->sg_init[1] = cfg->oe_min0;
+        s->sg_init[2] = cfg->oe_max0;
+        s->lds_strength = (size_t)(3 * M + 2) * 8 + (size_t)B * C * 4 + 64 * 4;
+        OFP_REQUIRE(s->lds_strength <= 160 * 1024, "ofp_hop_create: the hop (%d x %d samples) does not fit the LDS", B, C);
+    }
     // Fused form (one launch per hop, hop and result block in pinned host memory) whenever the detector
     // fits one workgroup of the fused kernel; OFP_HOP_GRAPH=nodes keeps the five-node graph.
     {
@@ -471,7 +691,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
         const size_t par_lds = (size_t)3 * B * C * sizeof(float);
         s->fused = !(mode && mode[0] == 'n') && 2 * C <= fused_threads(s->n_fft) && C <= ofpstream::PAR_MAX_C &&
                    par_lds <= 96 * 1024;
-        s->lds_fused = std::max(s->lds, par_lds);
+        s->lds_fused = std::max(std::max(s->lds, par_lds), s->lds_strength);
         if (s->fused) {
             float* dev_hop = nullptr;
             unsigned char* dev_res = nullptr;
@@ -482,6 +702,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
             a.mel = reinterpret_cast<float*>(dev_res + s->o_mel);
             a.count = reinterpret_cast<int64_t*>(dev_res + s->o_count);
             a.hop_index = reinterpret_cast<int64_t*>(dev_res + s->o_index);
+            if (a.sg.enabled) a.sg.out = reinterpret_cast<float*>(dev_res + s->o_sg);
             a.done_flag = reinterpret_cast<volatile int64_t*>(dev_res + s->o_done);
             ofpstream::StreamArgs& q = s->sargs;
             q = ofpstream::make_stream_args(det);
@@ -547,7 +768,7 @@ int ofp_hop_submit(ofp_hop_session* s, const float* h_hop) {
 }
 
 int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records, float* h_logits, float* h_mel,
-                    float* h_rel) {
+                    float* h_rel, float* h_strength) {
     OFP_REQUIRE(s, "ofp_hop_collect: NULL session");
     OFP_REQUIRE(s->in_flight, "ofp_hop_collect: no hop in flight");
     if (s->fused) {
@@ -577,14 +798,15 @@ int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records,
     if (h_logits && s->n_out) std::memcpy(h_logits, r + s->o_logits, (size_t)s->C * s->n_out * 4);
     if (h_mel) std::memcpy(h_mel, r + s->o_mel, (size_t)s->C * s->n_mels * 4);
     if (h_rel && s->want_rel) std::memcpy(h_rel, r + s->o_rel, (size_t)s->B * s->C * 4);
+    if (h_strength && s->args.sg.enabled) std::memcpy(h_strength, r + s->o_sg, 16);
     return OFP_OK;
 }
 
 int ofp_hop_push(ofp_hop_session* s, const float* h_hop, int64_t* n_onsets, ofp_onset* h_records, float* h_logits,
-                 float* h_mel, float* h_rel) {
+                 float* h_mel, float* h_rel, float* h_strength) {
     int rc = ofp_hop_submit(s, h_hop);
     if (rc != OFP_OK) return rc;
-    return ofp_hop_collect(s, n_onsets, h_records, h_logits, h_mel, h_rel);
+    return ofp_hop_collect(s, n_onsets, h_records, h_logits, h_mel, h_rel, h_strength);
 }
 
 int ofp_hop_ring_read(ofp_hop_session* s, int64_t n_rows, float* h_out) {

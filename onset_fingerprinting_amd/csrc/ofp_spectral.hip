@@ -85,8 +85,12 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
     float2* A = bufs + (size_t)sub * M;
+    // segment table of the band sums (ofp_fft.h: mel_bands) and one array of partial sums per frame slot
+    MelSegs* segs = reinterpret_cast<MelSegs*>((reinterpret_cast<uintptr_t>(foff + mf.n_mels) + 15) & ~(uintptr_t)15);
+    float* partial = reinterpret_cast<float*>(segs + 1) + (size_t)sub * MEL_MAXSEG;
+    if (mf.on && threadIdx.x == 0) mel_build_segs(segs, mf.len, mf.n_mels);
     // classifier epilogue: parameters, one tile A and 16 frame indices per tile group
-    float* mprm = reinterpret_cast<float*>(foff + mf.n_mels);
+    float* mprm = reinterpret_cast<float*>(segs + 1) + (size_t)FPW * MEL_MAXSEG;
     float* tileA = nullptr;
     float* tileB = nullptr;
     long long* rowf = nullptr;
@@ -140,43 +144,44 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         }
         fetch(grp + gridDim.x);
         cfft<M, T>(A, twM, tid);
-        constexpr int NK = M / T + 1;  // bins per lane: k = tid, tid + T, ... <= M
-        float pk[NK];
+        // power spectrum, two bins (p, M - p) per pair of the packed transform: pairs p = tid, tid + T, ... <= M/2
+        constexpr int NQ = (M / 2) / T + 1;
+        float pa[NQ], pb[NQ];
 #pragma unroll
-        for (int q = 0; q < NK; ++q) {
-            const int k = tid + q * T;
-            pk[q] = 0.0f;
-            if (k <= M) {
-                const float2 X = rfft_bin<M>(A, twF, k);
-                pk[q] = X.x * X.x + X.y * X.y;
-            }
+        for (int q = 0; q < NQ; ++q) {
+            const int pp = tid + q * T;
+            pa[q] = pb[q] = 0.0f;
+            if (pp <= M / 2) rfft_power_pair<M>(A, twF, pp, pa[q], pb[q]);
         }
         if (valid && power) {
             float* dst = power + f * (M + 1);
 #pragma unroll
-            for (int q = 0; q < NK; ++q)
-                if (tid + q * T <= M) dst[tid + q * T] = pk[q];
+            for (int q = 0; q < NQ; ++q) {
+                const int pp = tid + q * T;
+                if (pp <= M / 2) {
+                    dst[pp] = pa[q];
+                    if (pp < M / 2) dst[M - pp] = pb[q];
+                }
+            }
         }
         if (mf.on) {
             frame_sync<T>();  // every bin of the spectrum has been read
             float* pf = reinterpret_cast<float*>(A);
 #pragma unroll
-            for (int q = 0; q < NK; ++q)
-                if (tid + q * T <= M) pf[tid + q * T] = pk[q];
-            frame_sync<T>();
-            const int row = MLP ? it_tile * TC::FG + (sub % TC::FG) : 0;
-            if (valid) {
-                for (int b = tid; b < mf.n_mels; b += T) {  // same summation order as k_mel
-                    const float* p = pf + flo[b];
-                    const float* wb = fw + foff[b];
-                    float acc = 0.0f;
-                    const int nb_ = flen[b];
-#pragma unroll 4
-                    for (int k = 0; k < nb_; ++k) acc = fmaf(p[k], wb[k], acc);
-                    if (mf.mel) mf.mel[f * mf.n_mels + b] = acc;
-                    if (MLP) tileA[row * ml.plan.st_a + b] = acc;
+            for (int q = 0; q < NQ; ++q) {
+                const int pp = tid + q * T;
+                if (pp <= M / 2) {
+                    pf[pp] = pa[q];
+                    if (pp < M / 2) pf[M - pp] = pb[q];
                 }
             }
+            frame_sync<T>();
+            const int row = MLP ? it_tile * TC::FG + (sub % TC::FG) : 0;
+            mel_bands(segs, pf, fw, flo, flen, foff, mf.n_mels, tid, T, partial, [] { frame_sync<T>(); },
+                      [&](int b, float acc) {
+                          if (valid && mf.mel) mf.mel[f * mf.n_mels + b] = acc;
+                          if (MLP) tileA[row * ml.plan.st_a + b] = acc;
+                      });
             if (MLP && tid == 0) rowf[row] = valid ? (long long)f : -1;
         }
         if (MLP) {
@@ -288,10 +293,14 @@ __global__ __launch_bounds__(256) void k_mel(const float* __restrict__ power, in
          i += (int64_t)gridDim.x * blockDim.x) {
         int b = (int)(i % n_mels);
         int64_t r = i / n_mels;
-        const float* p = power + r * n_bins + lo[b];
-        const float* wb = w + off[b];
+        // the band sum as ofp_fft.h defines it: 32-tap segments, each a chain from 0, added in order
+        const float* pf = power + r * n_bins;
+        const int nseg = (len[b] + MEL_SEG - 1) / MEL_SEG;
         float acc = 0.0f;
-        for (int k = 0; k < len[b]; ++k) acc = fmaf(p[k], wb[k], acc);
+        for (int q = 0; q < nseg; ++q) {
+            const float part = mel_segment(pf, w, lo, len, off, b, q);
+            acc = q == 0 ? part : acc + part;
+        }
         mel[i] = acc;
     }
 }
@@ -333,7 +342,7 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
     using G = Cfg<F>;
     using TC = TileCfg<F>;
     size_t lds = G::lds_bytes;
-    if (mf.on) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4;
+    if (mf.on) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4 + 16 + sizeof(MelSegs) + (size_t)G::FPW * MEL_MAXSEG * 4;
     if (MLP) {
         // tile B lives in the tile group's idle FFT buffers
         OFP_REQUIRE((size_t)16 * ml.plan.st_b * 4 <= (size_t)TC::FG * G::M * 8,
@@ -416,6 +425,8 @@ int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int
                 "ofp_stft_power_mel: NULL / empty filterbank");
     OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel: filterbank with %d weights for %d bins", fb_nnz,
                 n_fft / 2 + 1);
+    OFP_REQUIRE(n_mels <= 127 && fb_nnz / MEL_SEG + n_mels <= MEL_MAXSEG, "ofp_stft_power_mel: at most 127 bands and %d 32-tap segments",
+                MEL_MAXSEG);
     MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1};
     return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream);
 }
@@ -428,6 +439,8 @@ int ofp_stft_power_mel_mlp(const float* d_x, int64_t n_clips, int64_t n_samples,
                 "ofp_stft_power_mel_mlp: NULL / empty filterbank");
     OFP_REQUIRE(fb_nnz <= 4 * (n_fft / 2 + 1), "ofp_stft_power_mel_mlp: filterbank with %d weights for %d bins", fb_nnz,
                 n_fft / 2 + 1);
+    OFP_REQUIRE(n_mels <= 127 && fb_nnz / MEL_SEG + n_mels <= MEL_MAXSEG, "ofp_stft_power_mel_mlp: at most 127 bands and %d 32-tap segments",
+                MEL_MAXSEG);
     OFP_REQUIRE(mlp && d_logits, "ofp_stft_power_mel_mlp: NULL classifier / output");
     OFP_REQUIRE(mlp->plan.dims[0] == n_mels, "ofp_stft_power_mel_mlp: the classifier takes %d inputs, the filterbank has %d bands",
                 mlp->plan.dims[0], n_mels);
@@ -476,6 +489,7 @@ int ofp_mel(const float* d_power, int64_t n_rows, int32_t n_bins, int32_t n_mels
             const int32_t* d_fb_len, const int32_t* d_fb_off, const float* d_fb_w, float* d_mel, void* stream) {
     if (n_rows == 0) return OFP_OK;
     OFP_REQUIRE(d_power && d_fb_lo && d_fb_len && d_fb_off && d_fb_w && d_mel, "ofp_mel: NULL argument");
+    OFP_REQUIRE(n_mels <= 127, "ofp_mel: at most 127 bands (got %d)", n_mels);
     int64_t total = n_rows * n_mels;
     unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 256 * 16);
     hipLaunchKernelGGL(k_mel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_power, n_rows, n_bins, n_mels,

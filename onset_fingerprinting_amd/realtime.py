@@ -53,7 +53,8 @@ class HopSession:
     def __init__(self, n_signals, block_size=128, sr=96000, n_fft=2048, n_mels=40, classifier=None,
                  ring_seconds=60.0, want_rel=False, device=0, floor=-70.0, hipass_freq=2000.0,
                  fast_ar=(3.0, 383.0), slow_ar=(2205.0, 2205.0), on_threshold=0.5, off_threshold=0.1,
-                 cooldown=1323, backtrack=False, backtrack_buffer_size=None, backtrack_smooth_size=5):
+                 cooldown=1323, backtrack=False, backtrack_buffer_size=None, backtrack_smooth_size=5,
+                 onset_strength=None):
         L = _lib.lib()
         self.n_signals, self.block_size, self.sr, self.n_fft, self.n_mels = n_signals, block_size, sr, n_fft, n_mels
         if backtrack_buffer_size is None:
@@ -76,6 +77,20 @@ class HopSession:
         cfg.mlp = mlp.handle if mlp is not None else None
         cfg.want_rel = int(bool(want_rel))
         self.want_rel = bool(want_rel)
+        # per-hop onset strength of the channel mean (realtime/recording.py:273-311; PARITY UNPINNED: its two
+        # trackers are loopmate.EMA_MinMaxTracker objects, loopmate is absent; see include/onsetfp.h).
+        # onset_strength: None, or a dict with max_length / avg_length (the reference's undefined
+        # config.MAX_LENGTH / AVG_LENGTH) and optionally ring, ls_* / oe_* tracker constants
+        self.onset_strength = None
+        if onset_strength is not None:
+            o = dict(ring=int(np.ceil(max(int(round(ring_seconds * sr)), n_fft) / block_size)), ls_max0=10.0,
+                     ls_minmax=0.0, ls_alpha=0.0005, oe_min0=0.0, oe_minmin=0.0, oe_max0=1.0, oe_alpha=0.001)
+            o.update(onset_strength)
+            cfg.strength = 1
+            cfg.strength_ring, cfg.max_length, cfg.avg_length = int(o["ring"]), int(o["max_length"]), int(o["avg_length"])
+            cfg.ls_max0, cfg.ls_minmax, cfg.ls_alpha = o["ls_max0"], o["ls_minmax"], o["ls_alpha"]
+            cfg.oe_min0, cfg.oe_minmin, cfg.oe_max0, cfg.oe_alpha = o["oe_min0"], o["oe_minmin"], o["oe_max0"], o["oe_alpha"]
+            self.onset_strength = o
         self.ring_samples = int(cfg.ring_samples)
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -87,6 +102,7 @@ class HopSession:
         self._logits = np.zeros((n_signals, max(self.n_out, 1)), dtype=np.float32)
         self._mel = np.zeros((n_signals, n_mels), dtype=np.float32)
         self._rel = np.zeros((block_size, n_signals), dtype=np.float32)
+        self._sg = np.zeros(4, dtype=np.float32)
         self.current_index = 0  # audio.py:120
 
     def close(self):
@@ -127,12 +143,15 @@ class HopSession:
     def collect(self):
         check(self._L.ofp_hop_collect(self.handle, ctypes.byref(self._n), self._rec.ctypes.data,
                                       self._logits.ctypes.data if self.n_out else None, self._mel.ctypes.data,
-                                      self._rel.ctypes.data if self.want_rel else None), "ofp_hop_collect")
+                                      self._rel.ctypes.data if self.want_rel else None,
+                                      self._sg.ctypes.data if self.onset_strength else None), "ofp_hop_collect")
         k = min(int(self._n.value), self.n_signals)
         self.current_index += self.block_size
         return dict(channels=self._rec["channel"][:k].astype(np.int64), onsets=self._rec["sample"][:k].copy(),
                     logits=self._logits.copy() if self.n_out else None, mel=self._mel.copy(),
-                    rel=self._rel.copy() if self.want_rel else None)
+                    rel=self._rel.copy() if self.want_rel else None,
+                    # {flux, normalised, moving max, moving mean} of recording.py:296-311
+                    strength=self._sg.copy() if self.onset_strength else None)
 
     def __call__(self, hop):
         self.submit(hop)
@@ -143,7 +162,8 @@ class HopSession:
         of onsets; the outputs stay in the session's host arrays."""
         check(self._L.ofp_hop_push(self.handle, hop.ctypes.data, ctypes.byref(self._n), self._rec.ctypes.data,
                                    self._logits.ctypes.data if self.n_out else None, self._mel.ctypes.data,
-                                   self._rel.ctypes.data if self.want_rel else None), "ofp_hop_push")
+                                   self._rel.ctypes.data if self.want_rel else None,
+                                   self._sg.ctypes.data if self.onset_strength else None), "ofp_hop_push")
         self.current_index += self.block_size
         return int(self._n.value)
 

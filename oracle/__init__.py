@@ -41,4 +41,4 @@ from .classifier import cccnn_forward, cnn_forward, fcnn_forward  # noqa: F401
 from .groups import find_onset_groups, group_windows  # noqa: F401
 from .xcorr import (adjust_onset, adjust_onset_rel, cross_correlation_lag, detect_onset_region,  # noqa: F401
                     filter_data, fix_onsets, lag_window, xcorr_slice)
-from .spectral_onsets import detect_onsets_spectral, librosa_stft_mag, peak_pick  # noqa: F401
+from .spectral_onsets import EMAMinMax, HopStrength, detect_onsets_spectral, librosa_stft_mag, peak_pick  # noqa: F401

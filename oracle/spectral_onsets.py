@@ -65,3 +65,57 @@ def detect_onsets_spectral(x, n_fft=256, hop=32, sr=96000, return_oe=False):
                       post_avg=0.01 * sr // hop + 1, delta=0.1, wait=sr * 0.07 // hop)
     peaks = peaks * hop
     return (peaks, oe) if return_oe else peaks
+
+
+class EMAMinMax:
+    """ASSUMED arithmetic of loopmate's EMA_MinMaxTracker (absent; realtime/recording.py:251-256): the update of
+    envelope_follower.c:27-57 with a single alpha, optional lower bounds for the two tracked values.  PARITY
+    UNPINNED: nothing in the reference or its tests fixes this class."""
+
+    def __init__(self, min0=0.0, max0=1.0, alpha=0.001, minmin=None, minmax=None):
+        self.min_val, self.max_val, self.alpha = np.float32(min0), np.float32(max0), np.float32(alpha)
+        self.minmin, self.minmax = minmin, minmax
+
+    def add_sample(self, x):
+        x, a = np.float32(x), self.alpha
+        self.max_val = x if x > self.max_val else (np.float32(1) - a) * self.max_val + a * x
+        self.min_val = x if x < self.min_val else (np.float32(1) - a) * self.min_val + a * x
+        if self.minmax is not None:
+            self.max_val = max(self.max_val, np.float32(self.minmax))
+        if self.minmin is not None:
+            self.min_val = max(self.min_val, np.float32(self.minmin))
+
+    def normalize_sample(self, x):
+        return (np.float32(x) - self.min_val) / (self.max_val - self.min_val)
+
+
+class HopStrength:
+    """RecAnalysis.fft + onset_strength per hop (realtime/recording.py:273-311) on a plain history array.
+    max_length / avg_length stand for config.MAX_LENGTH / AVG_LENGTH, which realtime/config.py does not define."""
+
+    def __init__(self, n_fft, n_channels, max_length, avg_length, ring):
+        from scipy.signal.windows import hann
+        self.n_fft = n_fft
+        self.window = hann(n_fft).astype(np.float32)                       # :249
+        self.audio = np.zeros((n_fft, n_channels), np.float32)             # audio[-n_fft:] of the ring buffer
+        self.prev = np.zeros(n_fft // 2 + 1, np.float32)
+        self.logspec = EMAMinMax(max0=10.0, minmax=0.0, alpha=0.0005)      # :254-256 (min side unused)
+        self.oe = EMAMinMax(min0=0.0, minmin=0.0, max0=1.0, alpha=0.001)   # :251-253
+        self.env = np.zeros(ring, np.float32)
+        self.max_length, self.avg_length = max_length, avg_length
+
+    def __call__(self, hop):
+        self.audio = np.concatenate([self.audio, hop])[-self.n_fft:]
+        X = np.fft.rfft((self.window * self.audio.mean(-1)).astype(np.float64))   # :276
+        mag = (X.real ** 2 + X.imag ** 2).astype(np.float32)
+        s = 10.0 * np.log10(np.maximum(1e-10, mag))                        # :290
+        self.logspec.add_sample(s.max())
+        floor = self.logspec.max_val - 80
+        s = np.maximum(s, floor)
+        sm1 = np.maximum(10.0 * np.log10(np.maximum(1e-10, self.prev)), floor)
+        onset_env = np.maximum(0.0, s - sm1).mean()                        # :296
+        self.prev = mag
+        self.oe.add_sample(onset_env)
+        norm = self.oe.normalize_sample(onset_env)
+        self.env = np.concatenate([self.env[1:], [norm]]).astype(np.float32)
+        return np.array([onset_env, norm, self.env[-self.max_length:].max(), self.env[-self.avg_length:].mean()])

@@ -194,3 +194,28 @@ def test_phase_split_block_kernel_equals_the_one_lane_per_channel_kernel(kw, mon
     odet.init_minmax_tracker(x[: 4000])
     exp = np.concatenate([odet(np.ascontiguousarray(x[i * B:(i + 1) * B]))[2] for i in range(nb - 0)][: k])
     assert np.array_equal(bits(outs[1][0][: k * B]), bits(exp))
+
+
+@pytest.mark.parametrize("graph", ["fused", "nodes"])
+def test_per_hop_onset_strength_matches_the_oracle_restatement(graph, monkeypatch):
+    """N1, second half (realtime/recording.py:273-311): channel-mean frame, dB flux, tracked normalisation,
+    moving max / mean, once per hop inside the session's graph.  PARITY UNPINNED: the trackers'
+    arithmetic is assumed (loopmate is absent); the GPU is checked against the oracle's restatement of the
+    same assumption at 1e-4 relative (+ 1e-6 absolute for values that are differences of dB terms)."""
+    from onset_fingerprinting_amd import realtime
+    monkeypatch.setenv("OFP_HOP_GRAPH", graph)
+    C, B, sr, F = 3, 128, 96000, 2048
+    x = synth.drum_hits(C, 0.6, sr, seed=31, period=0.09)
+    sess = realtime.HopSession(C, B, sr=sr, n_fft=F, ring_seconds=1.0, onset_strength=dict(max_length=12, avg_length=40, ring=64),
+                               **realtime.REALTIME_DETECTOR_KWARGS)
+    ref = oracle.HopStrength(F, C, 12, 40, 64)
+    worst = 0.0
+    for i in range(len(x) // B):
+        hop = np.ascontiguousarray(x[i * B:(i + 1) * B])
+        got = sess(hop)["strength"]
+        want = ref(hop)
+        err = np.abs(got - want) / (np.abs(want) + 1e-2)   # (flux values are means of dB differences of O(1))
+        worst = max(worst, float(err.max()))
+        assert err.max() < RTOL, (i, got, want)
+    assert worst > 0 and len(x) // B > 400
+    sess.close()
