@@ -54,20 +54,6 @@ struct TileCfg {
     static constexpr int ITERS = 16 / FG;        // iterations that fill a 16-row tile
 };
 
-// The classifier pass over a filled tile, kept OUT of line: inlined, its registers raised the pressure of the
-// FFT loop (2048-point frames: 255 VGPRs and copies through the accumulator file, 212 -> 143 M frames/s);
-// it runs once per 16 frames, a call costs nothing there.
-__device__ __attribute__((noinline)) void mlp_flush(const MlpPlan* plan, const float* mprm, float* tileA, float* tileB,
-                                                    long long* rowf, float* logits, int lane) {
-    const int nout = plan->dims[plan->n_layers];
-    ofp_mlp_tile(*plan, mprm, tileA, tileB, lane, [&](int r, int col, float v) {
-        const long long fr = rowf[r];
-        if (fr >= 0) logits[fr * nout + col] = v;
-    });
-    ofp_wave_lds_sync();
-    if (lane < 16) rowf[lane] = -1;
-}
-
 template <int F, bool MLP>
 __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
@@ -156,12 +142,8 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             const int n = tid + q * T;
             A[n] = make_float2(nx[q].x * win[2 * n], nx[q].y * win[2 * n + 1]);
         }
-        // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
-        // frames on one wave), where keeping them live across the passes costs more registers than the kernel has
-        // (copies through the accumulator file): those are fetched after the passes, in flight during the epilogue
-        if constexpr (NP <= 8) fetch(grp + gridDim.x);
+        fetch(grp + gridDim.x);
         cfft<M, T>(A, twM, tid);
-        if constexpr (NP > 8) fetch(grp + gridDim.x);
         // power spectrum, two bins (p, M - p) per pair of the packed transform: pairs p = tid, tid + T, ... <= M/2
         constexpr int NQ = (M / 2) / T + 1;
         float pa[NQ], pb[NQ];
@@ -207,7 +189,16 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             it_tile += 1;
             if (it_tile == TC::ITERS || grp + gridDim.x >= n_groups) {
                 frame_sync<TC::TG>();  // tile A complete; the group's FFT buffers are idle
-                if ((threadIdx.x % TC::TG) < 64) mlp_flush(&ml.plan, mprm, tileA, tileB, rowf, ml.logits, threadIdx.x & 63);
+                if ((threadIdx.x % TC::TG) < 64) {
+                    const int lane = threadIdx.x & 63;
+                    const int nout = ml.plan.dims[ml.plan.n_layers];
+                    ofp_mlp_tile(ml.plan, mprm, tileA, tileB, lane, [&](int r, int col, float v) {
+                        const long long fr = rowf[r];
+                        if (fr >= 0) ml.logits[fr * nout + col] = v;
+                    });
+                    ofp_wave_lds_sync();
+                    if (lane < 16) rowf[lane] = -1;
+                }
                 frame_sync<TC::TG>();  // tile B (the FFT buffers) is free again
                 it_tile = 0;
             }
