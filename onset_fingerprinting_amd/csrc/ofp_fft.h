@@ -152,6 +152,8 @@ struct Cfg {
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
     // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
     static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * M * 8;
+    // (k_stft_power keeps half the window, see build_half_window)
+    static constexpr size_t lds_bytes_half_window = (size_t)(M + M + 2) * 8 + (size_t)(F / 2 + 4) * 4 + (size_t)FPW * M * 8;
 };
 
 template <int F>
@@ -178,6 +180,15 @@ __device__ __forceinline__ void build_tables(float2* twM, float2* twF, float* wi
         }
     }
 }
+
+// The periodic Hann window w[n] = 0.5 - 0.5 cos(2 pi n / F) is symmetric about n = F/2 (w[n] = w[F - n], the same
+// bits: cospi(2 - x) and cospi(x) reduce to the same argument), so F/2 + 1 entries serve all F samples.
+template <int F>
+__device__ __forceinline__ void build_half_window(float* win) {
+    for (int n = threadIdx.x; n <= F / 2; n += blockDim.x) win[n] = (float)(0.5 - 0.5 * cospi(2.0 * (double)n / (double)F));
+}
+template <int F>
+__device__ __forceinline__ float half_window(const float* win, int n) { return win[n <= F / 2 ? n : F - n]; }
 
 // X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
 template <int M>

@@ -84,7 +84,11 @@ __global__ void k_hop_begin(HopArgs a) {
 
 template <int F>
 __global__ void k_hop_tables(float2* twM, float2* twF, float* win, float* wsym) {
-    build_tables<F>(twM, twF, win, F);
+    build_tables<F>(twM, twF, nullptr, F);
+    // the periodic Hann exactly as k_stft_power holds it: F/2 + 1 computed entries, mirrored above
+    for (int n = threadIdx.x; n <= F / 2; n += blockDim.x) win[n] = (float)(0.5 - 0.5 * cospi(2.0 * (double)n / (double)F));
+    __syncthreads();
+    for (int n = F / 2 + 1 + threadIdx.x; n < F; n += blockDim.x) win[n] = win[F - n];
     for (int n = threadIdx.x; n < F; n += blockDim.x)  // symmetric Hann (recording.py:249), fp64 then float32
         wsym[n] = (float)(0.5 - 0.5 * cospi(2.0 * (double)n / (double)(F - 1)));
 }

@@ -33,6 +33,7 @@ struct MelFuse {
     int n_mels, nnz;
     float* mel;  // [total_frames][n_mels]; NULL: no mel output
     int on;      // take the band sums (mel output and / or the classifier epilogue)
+    int seg_stride;  // floats of partial sums per frame slot: an upper bound of the 32-tap segments (nnz / 32 + n_mels)
 };
 
 // Classifier epilogue (MLP = true): the band sums of 16 frames are collected in an LDS tile per
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     extern __shared__ __align__(16) unsigned char smem[];
     float2* twM = reinterpret_cast<float2*>(smem);
     float2* twF = twM + M;
-    float* win = reinterpret_cast<float*>(twF + M + 2);
-    float2* bufs = reinterpret_cast<float2*>(win + F);
+    float* win = reinterpret_cast<float*>(twF + M + 2);   // half table: the periodic Hann is symmetric, w[n] = w[F - n]
+    float2* bufs = reinterpret_cast<float2*>(win + F / 2 + 4);
     // mel epilogue: the filterbank; a frame's power spectrum is written back into its FFT buffer
     // (M+1 floats fit into M float2) once every lane holds its bins in registers
     float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * M);
@@ -81,16 +82,17 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
             foff[i] = mf.off[i];
         }
     }
-    build_tables<F>(twM, twF, win, F);
+    build_tables<F>(twM, twF, nullptr, F);
+    build_half_window<F>(win);
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
     float2* A = bufs + (size_t)sub * M;
     // segment table of the band sums (ofp_fft.h: mel_bands) and one array of partial sums per frame slot
     MelSegs* segs = reinterpret_cast<MelSegs*>((reinterpret_cast<uintptr_t>(foff + mf.n_mels) + 15) & ~(uintptr_t)15);
-    float* partial = reinterpret_cast<float*>(segs + 1) + (size_t)sub * MEL_MAXSEG;
+    float* partial = reinterpret_cast<float*>(segs + 1) + (size_t)sub * mf.seg_stride;
     if (mf.on && threadIdx.x == 0) mel_build_segs(segs, mf.len, mf.n_mels);
     // classifier epilogue: parameters, one tile A and 16 frame indices per tile group
-    float* mprm = reinterpret_cast<float*>(segs + 1) + (size_t)FPW * MEL_MAXSEG;
+    float* mprm = reinterpret_cast<float*>(segs + 1) + (size_t)FPW * mf.seg_stride;
     float* tileA = nullptr;
     float* tileB = nullptr;
     long long* rowf = nullptr;
@@ -140,10 +142,14 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = tid + q * T;
-            A[n] = make_float2(nx[q].x * win[2 * n], nx[q].y * win[2 * n + 1]);
+            A[n] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
         }
-        fetch(grp + gridDim.x);
+        // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
+        // frames on one wave), where keeping them live across the passes costs more registers than the kernel
+        // has: those are fetched after the passes, in flight during the epilogue
+        if constexpr (NP <= 8) fetch(grp + gridDim.x);
         cfft<M, T>(A, twM, tid);
+        if constexpr (NP > 8) fetch(grp + gridDim.x);
         // power spectrum, two bins (p, M - p) per pair of the packed transform: pairs p = tid, tid + T, ... <= M/2
         constexpr int NQ = (M / 2) / T + 1;
         float pa[NQ], pb[NQ];
@@ -341,8 +347,8 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
                    const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
     using G = Cfg<F>;
     using TC = TileCfg<F>;
-    size_t lds = G::lds_bytes;
-    if (mf.on) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4 + 16 + sizeof(MelSegs) + (size_t)G::FPW * MEL_MAXSEG * 4;
+    size_t lds = G::lds_bytes_half_window;
+    if (mf.on) lds += (size_t)mf.nnz * 4 + (size_t)3 * mf.n_mels * 4 + 16 + sizeof(MelSegs) + (size_t)G::FPW * mf.seg_stride * 4;
     if (MLP) {
         // tile B lives in the tile group's idle FFT buffers
         OFP_REQUIRE((size_t)16 * ml.plan.st_b * 4 <= (size_t)TC::FG * G::M * 8,
@@ -427,7 +433,7 @@ int ofp_stft_power_mel(const float* d_x, int64_t n_clips, int64_t n_samples, int
                 n_fft / 2 + 1);
     OFP_REQUIRE(n_mels <= 127 && fb_nnz / MEL_SEG + n_mels <= MEL_MAXSEG, "ofp_stft_power_mel: at most 127 bands and %d 32-tap segments",
                 MEL_MAXSEG);
-    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1};
+    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1, ((fb_nnz / MEL_SEG + n_mels + 3) & ~3)};
     return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream);
 }
 
@@ -444,7 +450,7 @@ int ofp_stft_power_mel_mlp(const float* d_x, int64_t n_clips, int64_t n_samples,
     OFP_REQUIRE(mlp && d_logits, "ofp_stft_power_mel_mlp: NULL classifier / output");
     OFP_REQUIRE(mlp->plan.dims[0] == n_mels, "ofp_stft_power_mel_mlp: the classifier takes %d inputs, the filterbank has %d bands",
                 mlp->plan.dims[0], n_mels);
-    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1};
+    MelFuse mf{d_fb_lo, d_fb_len, d_fb_off, d_fb_w, n_mels, fb_nnz, d_mel, 1, ((fb_nnz / MEL_SEG + n_mels + 3) & ~3)};
     MlpFuse ml{mlp->plan, d_logits};
     return stft_power_impl(d_x, n_clips, n_samples, C, n_fft, hop, d_power, mf, planar_stride, stream, &ml);
 }
