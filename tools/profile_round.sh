@@ -13,7 +13,7 @@ timeout -k 10 300 $B --clips 1 --inflight 1 --no-cpu --no-extras > $O/bench_one_
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --no-cpu --no-extras > $O/bench_under_rocprof.json 2> $O/stats.err
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -1) $O/kernel_stats.csv
 # counters per launch do not depend on what else is in flight: one step at a time
-for W in "c2x1 --clips 1" "c2x8 --clips 8"; do
+for W in "c2x1 --clips 1" "c2x8 --clips 8" "c2x16 --clips 16"; do
   set -- $W; name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f_$name -- $B $@ --steps 2 --warmup 1 --no-cpu --no-extras --inflight 1 > $O/pmc_f_$name.json 2> $O/pmc_f_$name.err
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w_$name -- $B $@ --steps 2 --warmup 1 --no-cpu --no-extras --inflight 1 > $O/pmc_w_$name.json 2> $O/pmc_w_$name.err
@@ -29,7 +29,7 @@ OFP_HOP_GRAPH=nodes timeout -k 10 120 python3 $ROOT/tools/stream_latency.py --co
 head -c 900 $O/bench.json; echo; head -14 $O/kernel_stats.csv | cut -c1-150
 python3 - <<PY
 import json
-for n in ("c2x1", "c2x8"):
+for n in ("c2x1", "c2x8", "c2x16"):
     t = json.load(open("$O/pmc_traffic_per_kernel_%s.json" % n))
     tot = sum(v["hbm_mb_per_launch"] * v["calls"] for v in t.values())
     print(n, "PMC MB over the profiled run:", round(tot), {k: (v["calls"], round(v["hbm_mb_per_launch"])) for k, v in list(t.items())[:12]})
