@@ -468,7 +468,7 @@ def main():
         achieved = dom_bytes * frames_local / (dom_ms / 1e3) / 1e9
         stage_ms["hp_candidates(part of hp)"] = cand_ms
         traffic, traffic_src = None, None
-        if TRAFFIC_FILE.exists():
+        if TRAFFIC_FILE.exists() and workload == "c2" and n_local == 16:  # (the PMC passes were taken at 16 clips per launch)
             tj = json.load(open(TRAFFIC_FILE))
             key = {"hp": "k_hp_candidates", "stft_mel": "k_stft_power"}.get(dom)
             if key in tj:
