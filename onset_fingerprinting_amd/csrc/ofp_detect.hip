@@ -2130,6 +2130,9 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             const int G = d->t.verify_group > 0 ? (int)std::min<int64_t>(d->t.verify_group, 8) : (it == 0 ? 3 : 2);
             int* c = nullptr;
             if (int rc = ctr.take(2 * G, &c)) return rc;
+            // (a call that needs hundreds of rounds recycles the last counter slots, which are zeroed again: the
+            //  previous round's counters may be among them and would then read "nothing left" -- no skip check then)
+            if (c == ctr.base + OFP_N_COUNTERS - 16) last = nullptr;
             for (int q = 0; q < G; ++q) {
                 hc.counters = c + 2 * q;
                 hc.prev = last;
