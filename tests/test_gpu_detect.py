@@ -312,3 +312,13 @@ def test_g18_python_backtracking_on_the_gpu(det):
         x = synth.drum_hits(C, 2.0, SR, seed=180 + C + B, period=0.19)
         got = _stream_records(lambda: det.AmplitudeOnsetDetector(C, B, sr=SR, **kw), x, B, 4800)
         assert np.array_equal(got, g[f"{name}_records"]), name
+
+
+def test_hundreds_of_iir_verification_rounds_stay_exact(det):
+    """One candidate per chunk, no warm-up, tiny chunks: every chunk of the IIR stage is a break and a chain
+    advances one chunk per round -- more rounds than the call has counter slots, so slots are recycled.
+    (Found by the 1 500-case sweep of round 2: a recycled, re-zeroed slot was read as the previous round's
+    "nothing left" flag and the stage stopped early.)"""
+    x = synth.drum_hits(2, 6.5, SR, seed=77, period=0.31)
+    info, n = check_clip(det, x, tuning=dict(hp_chunk=1024, hp_warm=-1, hp_candidates=1), block_size=128, sr=SR)
+    assert info["hp_passes"] > 260 and n > 20
