@@ -112,24 +112,38 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     // loads of frame g+1 are in flight while frame g goes through the FFT
     constexpr int NP = M / T;  // sample pairs per lane
     float2 nx[NP];
+    // (frame index arithmetic in 32 bits: the host refuses more than 2^31 frames per launch; a 64-bit division
+    //  per frame costs more than a radix-8 butterfly)
+    const uint32_t H32 = (uint32_t)H, C32 = (uint32_t)C;
     auto fetch = [&](int64_t grp) {
         const int64_t f = grp * FPW + sub;
 #pragma unroll
         for (int q = 0; q < NP; ++q) nx[q] = make_float2(0.0f, 0.0f);
         if (grp < n_groups && f < total_frames) {
-            const int64_t h = f % H;
-            const int64_t cc = f / H;  // clip*C + c
-            const int c = (int)(cc % C);
-            const int64_t clip = cc / C;
-            // interleaved [clip][time][C] (the caller's layout: a lane's two samples sit in two 32-B
-            // sectors of which it uses 4 B) or planar [clip][C][time] (consecutive lanes, consecutive
-            // floats: the detector's transposed copy, 8x less L2 traffic at C = 8; `planar` = floats between series)
-            const int64_t stride = planar ? 1 : C;
-            const float* src = planar ? x + cc * planar + h * hop : x + (clip * n_samples + h * hop) * C + c;
+            const uint32_t cc = (uint32_t)f / H32;     // clip*C + c
+            const uint32_t h = (uint32_t)f - cc * H32;
+            if (planar) {
+                // planar [clip][C][time] (the detector's transposed copy): consecutive lanes, consecutive float
+                // pairs -- one 8-byte load per pair at a constant distance from the lane's first
+                const float2* src = reinterpret_cast<const float2*>(x + (int64_t)cc * planar + (int64_t)h * hop) + tid;
+                if ((reinterpret_cast<uintptr_t>(src) & 7u) == 0) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int n = tid + q * T;
-                nx[q] = make_float2(src[(int64_t)(2 * n) * stride], src[(int64_t)(2 * n + 1) * stride]);
+                    for (int q = 0; q < NP; ++q) nx[q] = src[q * T];
+                } else {  // odd hop or series offset: the pair straddles an 8-byte boundary
+                    const float* s1 = reinterpret_cast<const float*>(src);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) nx[q] = make_float2(s1[2 * q * T], s1[2 * q * T + 1]);
+                }
+            } else {
+                // interleaved [clip][time][C] (the caller's layout: a lane's two samples sit in two 32-B sectors of
+                // which it uses 4 B each)
+                const uint32_t clip = cc / C32, c = cc - clip * C32;
+                const float* src = x + ((int64_t)clip * n_samples + (int64_t)h * hop) * C + c;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int n = tid + q * T;
+                    nx[q] = make_float2(src[(int64_t)(2 * n) * C], src[(int64_t)(2 * n + 1) * C]);
+                }
             }
         }
     };
@@ -408,6 +422,7 @@ static int stft_power_impl(const float* d_x, int64_t n_clips, int64_t n_samples,
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t H = 1 + (n_samples - n_fft) / hop;
     const int64_t total = n_clips * C * H;
+    OFP_REQUIRE(total < (1ll << 31), "ofp_stft_power: %lld frames in one launch (at most 2^31 - 1)", (long long)total);
     switch (n_fft) {
         case 256: return launch_power<256>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
         case 512: return launch_power<512>(d_x, n_samples, C, hop, H, total, d_power, mf, planar, ml, stream);
