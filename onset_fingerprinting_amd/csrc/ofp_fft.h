@@ -90,6 +90,16 @@ __device__ __forceinline__ void frame_sync() {
     }
 }
 
+// LDS layout of a frame's M complex points: one pad word after every 16 (index w lives at w + w/16).  A wave's
+// 8-byte accesses are served 16 lanes at a time, conflict-free when those 16 words fall into 16 different bank
+// pairs: the pass-1 writes of the Stockham scheme go to words 8*lane + i (2 distinct bank pairs: 8-way
+// conflicts), the pass-2 writes to 64*(lane/8) + lane%8 + 8 i (8-way); with the pad they are conflict-free
+// and 2-way, and the unit-stride accesses stay conflict-free.  Measured before (rocprofv3 --pmc
+// SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_LDS): 321 M conflict cycles against 198 M active LDS cycles per launch.
+__device__ __forceinline__ constexpr int fft_pad(int w) { return w + (w >> 4); }
+template <int M>
+struct FftBuf { static constexpr int words = M + (M >> 4); };  // float2 slots of one frame's buffer
+
 template <int R, int M, int T>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
     constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
@@ -99,7 +109,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[b][i] = buf[j + i * (M / R)];
+        for (int i = 0; i < R; ++i) v[b][i] = buf[fft_pad(j + i * (M / R))];
     }
     frame_sync<T>();  // all reads of this pass are done
 #pragma unroll
@@ -114,7 +124,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
         dftR<R>(v[b]);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int i = 0; i < R; ++i) buf[j0 + i * Ns] = v[b][i];
+        for (int i = 0; i < R; ++i) buf[fft_pad(j0 + i * Ns)] = v[b][i];
     }
     frame_sync<T>();  // all writes are visible to the next pass
 }
@@ -151,9 +161,10 @@ struct Cfg {
     static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
     // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
-    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * M * 8;
+    static constexpr int MP = M + (M >> 4);                  // padded buffer of one frame (fft_pad)
+    static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * MP * 8;
     // (k_stft_power keeps half the window, see build_half_window)
-    static constexpr size_t lds_bytes_half_window = (size_t)(M + M + 2) * 8 + (size_t)(F / 2 + 4) * 4 + (size_t)FPW * M * 8;
+    static constexpr size_t lds_bytes_half_window = (size_t)(M + M + 2) * 8 + (size_t)(F / 2 + 4) * 4 + (size_t)FPW * MP * 8;
 };
 
 template <int F>
@@ -193,8 +204,8 @@ __device__ __forceinline__ float half_window(const float* win, int n) { return w
 // X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
 template <int M>
 __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, int k) {
-    float2 zk = Z[k & (M - 1)];
-    float2 zm = Z[(M - k) & (M - 1)];
+    float2 zk = Z[fft_pad(k & (M - 1))];
+    float2 zm = Z[fft_pad((M - k) & (M - 1))];
     zm.y = -zm.y;
     float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
     float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
@@ -208,8 +219,8 @@ __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, i
 // p = M/2 the two bins coincide (pb is then that bin again).
 template <int M>
 __device__ __forceinline__ void rfft_power_pair(const float2* Z, const float2* twF, int p, float& pa, float& pb) {
-    const float2 zk = Z[p & (M - 1)];
-    float2 zm = Z[(M - p) & (M - 1)];
+    const float2 zk = Z[fft_pad(p & (M - 1))];
+    float2 zm = Z[fft_pad((M - p) & (M - 1))];
     zm.y = -zm.y;
     const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
     const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     float2* bufs = reinterpret_cast<float2*>(win + F / 2 + 4);
     // mel epilogue: the filterbank; a frame's power spectrum is written back into its FFT buffer
     // (M+1 floats fit into M float2) once every lane holds its bins in registers
-    float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * M);
+    float* fw = reinterpret_cast<float*>(bufs + (size_t)FPW * G::MP);
     int32_t* flo = reinterpret_cast<int32_t*>(fw + mf.nnz);
     int32_t* flen = flo + mf.n_mels;
     int32_t* foff = flen + mf.n_mels;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     build_half_window<F>(win);
     const int sub = threadIdx.x / T;  // frame slot within the workgroup
     const int tid = threadIdx.x % T;
-    float2* A = bufs + (size_t)sub * M;
+    float2* A = bufs + (size_t)sub * G::MP;
     // segment table of the band sums (ofp_fft.h: mel_bands) and one array of partial sums per frame slot
     MelSegs* segs = reinterpret_cast<MelSegs*>((reinterpret_cast<uintptr_t>(foff + mf.n_mels) + 15) & ~(uintptr_t)15);
     float* partial = reinterpret_cast<float*>(segs + 1) + (size_t)sub * mf.seg_stride;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
         tileA = tiles + (size_t)grp_id * 16 * ml.plan.st_a;
         rowf = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(tiles + (size_t)TC::NGRP * 16 * ml.plan.st_a) + 7) &
                                             ~(uintptr_t)7) + grp_id * 16;
-        tileB = reinterpret_cast<float*>(bufs + (size_t)grp_id * TC::FG * M);
+        tileB = reinterpret_cast<float*>(bufs + (size_t)grp_id * TC::FG * G::MP);
         for (int i = threadIdx.x; i < ml.plan.n_params; i += blockDim.x) mprm[i] = ml.plan.params[i];
         if ((threadIdx.x % TC::TG) < 16) rowf[threadIdx.x % TC::TG] = -1;
     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = tid + q * T;
-            A[n] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
+            A[fft_pad(n)] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
         }
         // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
         // frames on one wave), where keeping them live across the passes costs more registers than the kernel
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
     for (int n = threadIdx.x; n < F; n += blockDim.x) win[n] = a.window[n];
     const int sub = threadIdx.x / T;
     const int tid = threadIdx.x % T;
-    float2* A = bufs + (size_t)sub * M;
+    float2* A = bufs + (size_t)sub * G::MP;
     const int lpad = (F - a.frame_length) / 2;  // librosa.util.pad_center (data.py:588-589)
     const int64_t n_groups = cdiv(a.n_frames, FPW);
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
                         s = src[idx * a.C];
                     v[e] = s * win[p];
                 }
-                A[n] = make_float2(v[0], v[1]);
+                A[fft_pad(n)] = make_float2(v[0], v[1]);
             }
         }
         cfft<M, T>(A, twM, tid);
