@@ -96,20 +96,33 @@ __device__ __forceinline__ void frame_sync() {
 // conflicts), the pass-2 writes to 64*(lane/8) + lane%8 + 8 i (8-way); with the pad they are conflict-free
 // and 2-way, and the unit-stride accesses stay conflict-free.  Measured before (rocprofv3 --pmc
 // SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_LDS): 321 M conflict cycles against 198 M active LDS cycles per launch.
-__device__ __forceinline__ constexpr int fft_pad(int w) { return w + (w >> 4); }
+// The pad costs a few address registers: frames of up to 1024 points have them to spare, the 2048-point frame on
+// one wave does not (it would drop from two waves per SIMD to one), so larger frames keep the plain layout.
 template <int M>
-struct FftBuf { static constexpr int words = M + (M >> 4); };  // float2 slots of one frame's buffer
+__device__ __forceinline__ constexpr int fft_pad(int w) { return M <= 512 ? w + (w >> 4) : w; }
+template <int M>
+struct FftBuf { static constexpr int words = M <= 512 ? M + (M >> 4) : M; };  // float2 slots of one frame's buffer
+
+// Offsets inside the padded layout are compile-time constants once the base word is padded: for a stride S that
+// is a multiple of 16, fft_pad(w + i S) = fft_pad(w) + i (S + S/16); the first pass writes words 8 j + i
+// (no carry into the next group of 16: + i), the second 64 a + k + 8 i with k < 8 (+ 8 i + i/2).
+template <int M>
+__device__ __forceinline__ constexpr int fft_pad_step(int Ns, int i) {
+    return M > 512 ? i * Ns : (Ns == 1 ? i : (Ns == 8 ? 8 * i + (i >> 1) : i * (Ns + (Ns >> 4))));
+}
 
 template <int R, int M, int T>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
     constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
     static_assert((M / R) % T == 0 && NB >= 1, "lanes per frame must divide the butterflies of a pass");
+    static_assert((M / R) % 16 == 0, "the read stride of a pass must be a multiple of the pad period");
     float2 v[NB][R];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
+        const float2* src = buf + fft_pad<M>(j);
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[b][i] = buf[fft_pad(j + i * (M / R))];
+        for (int i = 0; i < R; ++i) v[b][i] = src[i * ((M / R) + (M <= 512 ? (M / R) / 16 : 0))];
     }
     frame_sync<T>();  // all reads of this pass are done
 #pragma unroll
@@ -122,9 +135,9 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
             for (int i = 1; i < R; ++i) v[b][i] = cmul(v[b][i], tw[(i * tstep) & (M - 1)]);
         }
         dftR<R>(v[b]);
-        const int j0 = (j - k) * R + k;
+        float2* dst = buf + fft_pad<M>((j - k) * R + k);
 #pragma unroll
-        for (int i = 0; i < R; ++i) buf[fft_pad(j0 + i * Ns)] = v[b][i];
+        for (int i = 0; i < R; ++i) dst[fft_pad_step<M>(Ns, i)] = v[b][i];
     }
     frame_sync<T>();  // all writes are visible to the next pass
 }
@@ -161,7 +174,7 @@ struct Cfg {
     static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
     // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
-    static constexpr int MP = M + (M >> 4);                  // padded buffer of one frame (fft_pad)
+    static constexpr int MP = FftBuf<M>::words;              // (padded) buffer of one frame (fft_pad)
     static constexpr size_t lds_bytes = (size_t)(M + M + 2) * 8 + (size_t)F * 4 + (size_t)FPW * MP * 8;
     // (k_stft_power keeps half the window, see build_half_window)
     static constexpr size_t lds_bytes_half_window = (size_t)(M + M + 2) * 8 + (size_t)(F / 2 + 4) * 4 + (size_t)FPW * MP * 8;
@@ -204,8 +217,8 @@ __device__ __forceinline__ float half_window(const float* win, int n) { return w
 // X[k], k in [0, M], from the packed transform Z (split pass of the real FFT)
 template <int M>
 __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, int k) {
-    float2 zk = Z[fft_pad(k & (M - 1))];
-    float2 zm = Z[fft_pad((M - k) & (M - 1))];
+    float2 zk = Z[fft_pad<M>(k & (M - 1))];
+    float2 zm = Z[fft_pad<M>((M - k) & (M - 1))];
     zm.y = -zm.y;
     float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
     float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));
@@ -219,8 +232,8 @@ __device__ __forceinline__ float2 rfft_bin(const float2* Z, const float2* twF, i
 // p = M/2 the two bins coincide (pb is then that bin again).
 template <int M>
 __device__ __forceinline__ void rfft_power_pair(const float2* Z, const float2* twF, int p, float& pa, float& pb) {
-    const float2 zk = Z[fft_pad(p & (M - 1))];
-    float2 zm = Z[fft_pad((M - p) & (M - 1))];
+    const float2 zk = Z[fft_pad<M>(p & (M - 1))];
+    float2 zm = Z[fft_pad<M>((M - p) & (M - 1))];
     zm.y = -zm.y;
     const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
     const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y - zm.y));

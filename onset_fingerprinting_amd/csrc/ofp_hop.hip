@@ -152,7 +152,7 @@ __device__ __forceinline__ void hop_spectral_body(const HopArgs& a, int c, int64
         return a.ring[(s % a.R) * C + c];
     };
     for (int p = tid; p < M; p += WGS)
-        A[fft_pad(p)] = make_float2(sample(base + 2 * p) * win[2 * p], sample(base + 2 * p + 1) * win[2 * p + 1]);
+        A[fft_pad<M>(p)] = make_float2(sample(base + 2 * p) * win[2 * p], sample(base + 2 * p + 1) * win[2 * p + 1]);
     __syncthreads();
     if (tid < T) {
         cfft<M, T>(A, twM, tid);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void hop_strength_body(const HopArgs& a, int64_t h, u
         return m / (float)C;
     };
     for (int p = tid; p < M; p += WGS)
-        A[fft_pad(p)] = make_float2(g.wsym[2 * p] * mean_sample(base + 2 * p), g.wsym[2 * p + 1] * mean_sample(base + 2 * p + 1));
+        A[fft_pad<M>(p)] = make_float2(g.wsym[2 * p] * mean_sample(base + 2 * p), g.wsym[2 * p + 1] * mean_sample(base + 2 * p + 1));
     __syncthreads();
     constexpr int NK = M / T + 1;
     float pw[NK], sdb[NK];
@@ -594,7 +594,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     s->res_bytes = up8(s->o_sg + 16);
     const int M = s->n_fft / 2;
     const int st_a = cfg->mlp ? plan.st_a : 0, st_b = cfg->mlp ? plan.st_b : 0;
-    s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)(M + M / 16) * 8 + (size_t)cfg->fb_nnz * 4 +
+    s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)(M <= 512 ? M + M / 16 : M) * 8 + (size_t)cfg->fb_nnz * 4 +
              (size_t)3 * s->n_mels * 4 + 16 + sizeof(MelSegs) + (size_t)MEL_MAXSEG * 4 + (size_t)((plan.n_params + 3) & ~3) * 4 + (size_t)16 * (st_a + st_b) * 4 + (size_t)B * 4 + 64;
     int rc = OFP_OK;
     auto fail = [&](int code) {

@@ -12,6 +12,8 @@
 // the workgroup processes.  T = M/8 lanes cooperate on one frame, so a 1024-point
 // frame is exactly one 64-lane wavefront.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "ofp_common.h"
 #include "ofp_fft.h"
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = tid + q * T;
-            A[fft_pad(n)] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
+            A[fft_pad<M>(n)] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
         }
         // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
         // frames on one wave), where keeping them live across the passes costs more registers than the kernel
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_frames(FrameArgs a) {
                         s = src[idx * a.C];
                     v[e] = s * win[p];
                 }
-                A[fft_pad(n)] = make_float2(v[0], v[1]);
+                A[fft_pad<M>(n)] = make_float2(v[0], v[1]);
             }
         }
         cfft<M, T>(A, twM, tid);
@@ -372,6 +374,7 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
                (size_t)TC::NGRP * 16 * 8 + 16;
         OFP_REQUIRE(lds <= 160 * 1024, "classifier epilogue: %zu bytes of LDS needed, 160 KiB available", lds);
     }
+    if (getenv("OFP_DEBUG_LDS")) fprintf(stderr, "k_stft_power<%d,%d>: %zu bytes of LDS per workgroup\n", F, (int)MLP, lds);
     static size_t attr_set = 0;
     if (lds > 65536 && lds > attr_set) {
         OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F, MLP>),
