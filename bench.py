@@ -21,7 +21,7 @@ Workloads (BASELINE.json configs):
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
       (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
       the timed region) is the same 512 clips on one GPU -- the base the strong-scaling ratio refers to.
-`--inflight D` keeps D steps in flight per GPU (default 2 for c2; 3 / 4 / 8 for C4 shards of > 128 / <= 128 / <= 64 clips), each on its own pipeline instance with its own
+`--inflight D` keeps D steps in flight per GPU (default 3 for c2; 3 / 4 / 8 for C4 shards of > 128 / <= 128 / <= 64 clips), each on its own pipeline instance with its own
 DISTINCT clips, streams and host thread: while one batch sits in the latency-bound verification rounds
 of its detector the other keeps the chip busy.  The K timed steps are bracketed by barriers as the
 contract asks (the pipeline's ramp-up and drain are inside the window); `config.latency_ms_per_step` is what
@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c2", "c4"], default=None)
     ap.add_argument("--clips", type=int, default=16, help="c2: distinct clips per GPU and step")
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 2 for c2; 3 / 4 / 8 for c4 shards of > 128 / <= 128 / <= 64 clips)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 3 for c2; 3 / 4 / 8 for c4 shards of > 128 / <= 128 / <= 64 clips)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra figures (one clip per step, whole batch)")
@@ -276,7 +276,7 @@ def main():
     elif workload == "c4":
         D = 8 if n_local <= 64 else (4 if n_local <= 128 else 3)
     else:
-        D = 2
+        D = 3
 
     def barrier():
         if not rehearsal:
