@@ -114,12 +114,19 @@ def launch_ranks(n):
 
 
 def usable_cpus():
-    """Worker processes this run may start: the CPUs it is allowed on, at most 16 (a GPU box hands one GPU's
-    job 16 of its cores whatever os.cpu_count() says; every worker also holds its own copy of a clip)."""
+    """Worker processes this run may start: the CPUs it is allowed on (affinity mask and cgroup CPU quota), at most
+    16 (a GPU box hands one GPU's job 16 of its cores whatever os.cpu_count() says; every worker also holds its own
+    copy of a clip)."""
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
+    try:  # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     return max(1, min(16, n))
 
 
