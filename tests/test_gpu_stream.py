@@ -219,3 +219,22 @@ def test_per_hop_onset_strength_matches_the_oracle_restatement(graph, monkeypatc
         assert err.max() < RTOL, (i, got, want)
     assert worst > 0 and len(x) // B > 400
     sess.close()
+
+
+def test_wide_session_takes_the_five_node_graph_and_the_one_lane_kernel():
+    """200 channels x 64 samples: too many channels for the fused kernel's detector workgroup (2 C lanes) and too
+    large a block for the phase-split kernel's LDS (3 x B x C floats) -- the session falls back to the five-node
+    graph with the one-lane-per-channel block kernel and must give the same answers."""
+    from onset_fingerprinting_amd import realtime
+    C, B, sr, F = 200, 64, 48000, 256
+    x = synth.drum_hits(C, 0.12, sr, seed=5, period=0.03)
+    sess = realtime.HopSession(C, B, sr=sr, n_fft=F, ring_seconds=0.05, want_rel=True)
+    odet = oracle.OracleDetector(C, B, sr=sr)
+    got, exp, nb = replay(sess, odet, x, B)
+    assert got["ch"] == exp["ch"] and got["on"] == exp["on"] and len(exp["on"]) > 50
+    assert np.array_equal(bits(np.concatenate(got["rel"])), bits(np.concatenate(exp["rel"])))
+    P = oracle.dense_power_frames(x[nb * B - F: nb * B], F, B)[:, 0]
+    mel_ref = P @ oracle.mel_filterbank(sr, F, 40).astype(np.float64).T
+    big = mel_ref >= 1e-5 * mel_ref.max()
+    assert (np.abs(got["mel"][-1] - mel_ref)[big] / mel_ref[big]).max() < RTOL
+    sess.close()
