@@ -455,6 +455,7 @@ def main():
 
     if rank == 0:
         out, gathered = res
+        ranks_seen = int(gathered.shape[0])   # blocks the all-gather delivered: one per rank
         gathered = unpack_gathered(gathered)  # decode (and check) the last step's exchange
         recs = records_to_numpy(gathered)
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
@@ -498,7 +499,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": dict({"workload": wl, "clips_per_gpu_per_step": n_local, "clips_total_per_step": total_clips,
                             "frames_per_step": frames_total, "frames_per_gpu_per_step": frames_local,
-                            "onsets_gathered": int(len(recs)), "ranks_in_exchange": world, "backend": backend if world > 1 else "-",
+                            "onsets_gathered": int(len(recs)), "ranks_in_exchange": ranks_seen, "backend": backend if world > 1 else "-",
                             "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D, "detector_tuning": tuning or "library defaults",
                             "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
                             "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3)}, **extras),
