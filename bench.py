@@ -275,15 +275,21 @@ def main():
     # so it is sized for the largest shard
     n_local_max = n_local if workload == "c2" else -(-C4["clips"] // world)
     cap_block = n_local_max * (1024 if workload == "c2" else 256)
-    # steps in flight: small shards (a rank's 64 clips of C4 at 8 GPUs) are latency-bound and overlap well
-    # (measured on one GPU, bench.py --workload c4 --shard-of 8: 64 clips 9.0 / 7.3 / 6.1 / 5.6 ms per step at
-    # 1 / 2 / 4 / 8 in flight; 128 clips 10.7 / 9.5 ms at 2 / 4; 256 clips 18.5 / 17.4 ms at 2 / 3)
+    # steps in flight (measured on one GPU, tools/share_sweep*.sh, ms per step): a rank's 64 clips of C4 at 8
+    # GPUs 9.0 / 7.3 / 6.1 / 5.7 at 1 / 2 / 4 / 8 in flight and 4.6 at 12 with the layout hint below; 128 clips
+    # 9.8 at 4, 8.6 at 8 with the hint; 256 clips 17.8 at 3, 16.7 at 4; all 512: 32.1 / 30.7 / 29.2 at 3 / 4 / 6.
+    # C2 x 16: 12.9 / 12.2 / 11.7 at 3 / 4 / 6.
     if args.inflight > 0:
         D = args.inflight
     elif workload == "c4":
-        D = 8 if n_local <= 64 else (4 if n_local <= 128 else 3)
+        D = 12 if n_local <= 64 else (8 if n_local <= 128 else 4)
     else:
-        D = 3
+        D = 4
+    auto_tuning = {}
+    if workload == "c4" and n_local <= 128 and D >= 4:
+        # small shards, many calls in flight: each call lays its speculative passes out for a quarter of the
+        # GPU instead of as if it were alone (ofp_detect_tuning.concurrent_calls; results do not change)
+        auto_tuning = {"concurrent_calls": 4}
 
     def barrier():
         if not rehearsal:
@@ -308,7 +314,7 @@ def main():
         """c4, steps in flight: a distinct batch per slot derived on the device (channels rotated, gain changed)."""
         return (torch.roll(slot0[0], slot, dims=2) * (1.0 - 0.07 * slot)).contiguous(), None
 
-    tuning = json.loads(args.tuning) if args.tuning else {}
+    tuning = json.loads(args.tuning) if args.tuning else dict(auto_tuning)
     result_extra = {}
     if rehearsal:
         # fabricated detector output: 3 onsets per clip of this rank's shard
@@ -448,7 +454,7 @@ def main():
                 msw = (time.perf_counter() - tw) / nw * 1e3
             extras["whole_batch_on_one_gpu"] = {"ms_per_step": round(msw, 3), "frames_per_s": round(frames_total / (msw / 1e3)),
                                                 "strong_scaling_vs_it": round((msw / ms_per_step) / world, 3),
-                                                "note": "rank 0 alone on 512 clips (its shard tiled), after the timed region"}
+                                                "note": "rank 0 alone on 512 clips (its shard tiled), one step at a time, after the timed region; with steps in flight the whole batch takes 29-32 ms per step on one GPU (DESIGN.md section 6)"}
             del pw, xw
         if world > 1:
             dist.barrier()

@@ -122,6 +122,11 @@ typedef struct ofp_detect_tuning {
                                     (0: chosen from the batch size, see make_layout) */
     int64_t verify_group;        /* verification passes / rounds enqueued per host synchronisation (0: default 2-3;
                                     1: one host round trip per pass, the round-1 behaviour) */
+    int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
+                                    at once (0 / 1: this call has the GPU to itself).  The layout of the
+                                    speculative passes is chosen for the GPU's share: with k calls in flight each
+                                    gets 1/k of the lane budget, i.e. the work-efficient layout of a k times larger
+                                    batch instead of the latency layout of a lone call.  Results do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -1695,7 +1695,11 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // has parallelism to spare and pays for every redundant step instead, so candidates are traded
     // for chunk length until the launch is about two waves per SIMD.
     const int64_t chains = n_clips * g.C;
-    const int64_t lane_budget = 2 * 4 * 64 * (int64_t)d->n_cus;
+    // concurrent_calls: the caller keeps that many calls of this size in flight; each lays its passes out for
+    // its share of the GPU (the work-efficient layout of the larger batch they form together)
+    const int64_t share = std::max<int64_t>(1, d->t.concurrent_calls);
+    const int64_t cus = std::max<int64_t>(1, (int64_t)d->n_cus / share);
+    const int64_t lane_budget = 2 * 4 * 64 * cus;
     int64_t hpL = 8192, hpR = 16, arL = 4096, mmL = 4096;
     if (d->t.hp_chunk <= 0 && d->t.hp_candidates <= 0) {
         if (chains * cdiv(g.V, hpL) * hpR > lane_budget) hpR = 8;  // fewer leave too many chain breaks
@@ -1703,7 +1707,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     }
     // (followers: their chunk pass is the cheap part, the overlapping warm-up windows the expensive one, so the
     // chunks grow earlier -- at 3/4 of a wave per SIMD; measured on 512 clips x 4 ch: 6.2 -> 4.8 ms)
-    while (arL < 32768 && chains * cdiv(g.U, arL) > (int64_t)3 * 64 * d->n_cus) arL *= 2;
+    while (arL < 32768 && chains * cdiv(g.U, arL) > (int64_t)3 * 64 * cus) arL *= 2;
     while (mmL < 32768 && chains * cdiv(g.U, mmL) > lane_budget) mmL *= 2;
     l.hp_L = pick(d->t.hp_chunk, hpL);
     l.hp_W = pick_warm(d->t.hp_warm, 40960);
@@ -1717,7 +1721,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // warm-up between two chunks then does 2/3 of the steps in half the waves (measured, detector only:
     // 8 x C2 10.2 -> 8.9 ms, C4 36.6 -> 31.7 ms); a lone clip (720 waves) stays at 1, the latency setting.
     if (d->t.hp_span <= 0 && l.hp_R % 2 == 0 &&
-        chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * d->n_cus)
+        chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * cus)
         l.hp_span = 2;
     l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
     l.ar_L = pick(d->t.ar_chunk, arL);
@@ -1758,7 +1762,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
             const double walk = (double)(W + (cand[i] - 1) * L);
             const double groups = (double)cdiv(n_chunks, cand[i]);
             const double t_path = walk * ns_per_step * 1e-9;
-            const double t_mem = (double)chains * groups * walk * 4.0 / 3.0e12;
+            const double t_mem = (double)share * (double)chains * groups * walk * 4.0 / 3.0e12;
             t[i] = std::max(t_path, t_mem);
             best = std::min(best, t[i]);
         }
@@ -2090,7 +2094,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nC0 = chains * l.hp_chunks;
         if (do_cand) {
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
-            if ((int64_t)cand_grid <= d->n_cus)
+            if ((int64_t)cand_grid <= d->n_cus && d->t.concurrent_calls <= 1)
                 hipLaunchKernelGGL(k_hp_candidates<true>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
             else
                 hipLaunchKernelGGL(k_hp_candidates<false>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);

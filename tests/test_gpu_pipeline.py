@@ -73,6 +73,8 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
     for tuning in (None,
                    dict(hp_chunk=4096, hp_warm=16384, hp_candidates=3, ar_chunk=8192, ar_warm=30000, mm_chunk=4096, mm_warm=20000),
                    dict(hp_chunk=50000, hp_candidates=1, ar_chunk=100000, ar_coarse_warm=-1, mm_chunk=30000, mm_warm=100000),
+                   dict(concurrent_calls=8),   # the layout of a call that has an eighth of the GPU
+                   dict(concurrent_calls=64),
                    None):
         bd = detection.BatchDetector(8, 256, sr=SR)
         if tuning:
