@@ -122,6 +122,12 @@ typedef struct ofp_detect_tuning {
                                     (0: chosen from the batch size, see make_layout) */
     int64_t verify_group;        /* verification passes / rounds enqueued per host synchronisation (0: default 2-3;
                                     1: one host round trip per pass, the round-1 behaviour) */
+    int64_t hp_dedupe;           /* IIR stage: speculative candidates in stages with duplicate runs removed between
+                                    them (a third of the steps, six launches instead of one): 0 auto (batches whose
+                                    candidate launch is throughput-bound), 1 always, < 0 never */
+    int64_t hp_early;            /* IIR stage: a chunk re-run whole from its true start state stops at the first
+                                    sub-chunk boundary where it has joined a candidate's recorded trajectory:
+                                    0 auto (chunks of 32768 samples and more), 1 always, < 0 never */
     int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
                                     at once (0 / 1: this call has the GPU to itself).  The layout of the
                                     speculative passes is chosen for the GPU's share: with k calls in flight each
@@ -157,9 +163,10 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  * [OFP_DETECT_INFO_LEN]) receives {0: hp passes, 1: follower passes, 2: tracker
  * passes, 3: repaired chunks, 4..9: nanoseconds (HIP events on `stream`) spent in
  * the hp, dB, follower, linear, tracker and crossing/state-machine stages,
- * 10: total nanoseconds, 11: nanoseconds of the k_hp_candidates launch (the longest
- * single launch), 12: IIR steps that launch executes over all its lanes (17 fp32
- * operations each)}. */
+ * 10: total nanoseconds, 11: nanoseconds of the IIR candidate launch(es) (k_hp_candidates, the
+ * longest single launch; or the stages k_hp_seg0 .. k_hp_seg_chunk), 12: IIR steps they execute
+ * over all their lanes (17 fp32 operations each), 13: staged candidates only: distinct runs that
+ * walked a chunk, of chains * chunks * candidates}. */
 #define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,

@@ -57,6 +57,8 @@ class DetectTuning(ctypes.Structure):
         ("ar_span", ctypes.c_int64),
         ("mm_span", ctypes.c_int64),
         ("verify_group", ctypes.c_int64),
+        ("hp_dedupe", ctypes.c_int64),
+        ("hp_early", ctypes.c_int64),
         ("concurrent_calls", ctypes.c_int64),
     ]
 

@@ -772,6 +772,10 @@ struct HpCand {
     const int* prev;  // the counters of the preceding round, or NULL: both zero = the stage had converged,
                       // this round (enqueued ahead of the host's check) has nothing to do
     int32_t* pos;     // [clips][C] first chunk not yet resolved (resume point of the walk)
+    int8_t* mrg;      // [clips][chunks][C] early stop of a whole run: the candidate whose recorded trajectory the run from
+                      // the true start state joined at a sub-chunk boundary (the sub-chunks after it are written from
+                      // that candidate's inner states by the next round's lanes), -1 none
+    int early;        // whole runs stop at the first sub-chunk boundary where they have joined a candidate
     unsigned long long* probe;  // diagnostics (OFP_HP_PROBE): per wave {start, end (s_memtime), HW_ID, XCC_ID}; else NULL
     __device__ __host__ int64_t slot(int64_t clip, int64_t k, int c, int r) const {
         return ((((clip * st.n_chunks + k) * st.g.C + c) * (R + 1)) + r) * 4;
@@ -823,6 +827,7 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
         for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
         a.guessed[ci] = 0;
         a.ran[ci] = -2;
+        a.mrg[ci] = -1;
         a.U[a.slot(clip, j, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
         // slots of runs that would have started before the stream: never match, never agree
         for (int rr = (int)min<int64_t>((j + 1) * Rm, a.R); rr < a.R; ++rr) {
@@ -868,6 +873,162 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_candidates(HpCand a, int
         q[1] = __builtin_amdgcn_s_memtime();
         q[2] = (unsigned)__builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID: wave, simd, cu, sh, se ...
         q[3] = (unsigned)__builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+    }
+}
+
+// ---- the same candidates in STAGES with duplicates removed between them (throughput setting).
+// The R speculative runs of a chunk merge with EACH OTHER long before the chunk starts (measured on C2,
+// tools/cand_merge_stats.py: of 8 runs 4.8 are distinct after 8 192 steps, 3.0 after 16 384, 1.6 at the chunk
+// start), and two runs in the same state at the same position stay the same run for ever.  The warm-up is
+// therefore cut into segments; after each, k_hp_dedupe keeps one run per distinct state of a group (= the
+// candidates of one chunk) with the set of candidate slots it stands for, and compacts the work list, so that the
+// next segment's launch has a lane per DISTINCT run only.  The last stage walks the chunk itself and writes the
+// U / M / E records of every slot its run stands for: everything downstream sees exactly what k_hp_candidates
+// (span 1) would have written, with a third of the steps.
+struct HpRuns {
+    int32_t* grp;    // [n] group = chain * n_chunks + j
+    uint32_t* mask;  // [n] candidate slots of the group this run stands for
+    float4* z;       // [n] filter state at the common position of the stage
+};
+
+// stage 0: lane = (chain, chunk j, candidate r), r fastest: from its staggered start to window offset p1
+__global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg0(HpCand a, HpRuns out, int32_t* __restrict__ off,
+                                                              int32_t* __restrict__ cnt, int64_t p1, int64_t n_threads) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const HpArgs& st = a.st;
+    int64_t q = id;
+    const int r = (int)(q % a.R);
+    q /= a.R;
+    const int64_t grp = q;
+    const int64_t j = q % st.n_chunks;
+    const int64_t chain = q / st.n_chunks;
+    const int C = st.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
+    if (r == 0) {
+        const int64_t ci = (clip * st.n_chunks + j) * C + c;
+        a.sel[ci] = (j == 0) ? 0 : -1;
+        for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+        a.guessed[ci] = 0;
+        a.ran[ci] = -2;
+        a.mrg[ci] = -1;
+        a.U[a.slot(clip, j, c, a.R)] = 0x7fc00001u;  // slot R empty: a NaN pattern no state can equal
+        off[grp] = (int32_t)(grp * a.R);
+        cnt[grp] = a.R;
+    }
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    s.z[0] = s.z[1] = s.z[2] = s.z[3] = 0.0f;
+    if (a.delta == 0) s.z[0] = (float)r * 0.0009765625f;
+    const int64_t w0 = j * st.L - st.W;
+    const int64_t ws = max<int64_t>(w0 - (int64_t)r * a.delta, 0);
+    hp_span<false>(st, s, chain, ws, max<int64_t>(w0 + p1, 0));
+    out.grp[id] = (int32_t)grp;
+    out.mask[id] = 1u << r;
+    out.z[id] = make_float4(s.z[0], s.z[1], s.z[2], s.z[3]);
+}
+
+// between stages: 16 lanes per group, lane i holds run i of the group.  A run whose state equals (bitwise) that of
+// an earlier run of the group is dropped and its slot set joins that run's; the survivors are appended to the next
+// work list (a wave reserves its range with one atomic; a group's runs stay neighbours: they read the same samples)
+__global__ __launch_bounds__(256) void k_hp_dedupe(HpRuns in, HpRuns out, int32_t* __restrict__ off,
+                                                   int32_t* __restrict__ cnt, int64_t n_groups, int* __restrict__ n_out) {
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int i = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const bool live = g < n_groups;
+    const int o = live ? off[g] : 0, k = live ? cnt[g] : 0;
+    const bool have = i < k;
+    uint32_t z0 = 0, z1 = 0, z2 = 0, z3 = 0, mk = 0;
+    if (have) {
+        const float4 v = in.z[o + i];
+        z0 = ofp_f2u(v.x), z1 = ofp_f2u(v.y), z2 = ofp_f2u(v.z), z3 = ofp_f2u(v.w);
+        mk = in.mask[o + i];
+    }
+    int leader = i;
+    uint32_t all = 0;
+    for (int q = 0; q < 16; ++q) {  // (uniform trip count: every lane takes part in the shuffles)
+        const bool same = __shfl(z0, q, 16) == z0 && __shfl(z1, q, 16) == z1 && __shfl(z2, q, 16) == z2 &&
+                          __shfl(z3, q, 16) == z3 && q < k;
+        const uint32_t mq = __shfl(mk, q, 16);
+        if (same && have) {
+            all |= mq;
+            leader = min(leader, q);
+        }
+    }
+    const bool keep = have && leader == i;
+    const unsigned long long kept = __ballot(keep);
+    const int before = __popcll(kept & ((1ull << lane) - 1));  // survivors before me in the wave: groups stay in order
+    const int total = __popcll(kept);
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(n_out, total);
+    base = __shfl(base, 0);
+    const int gfirst = __popcll(kept & ((1ull << (lane & 48)) - 1));
+    if (live && i == 0) {
+        off[g] = base + gfirst;
+        cnt[g] = __popcll((kept >> (lane & 48)) & 0xffffull);
+    }
+    if (keep) {
+        out.grp[base + before] = (int32_t)g;
+        out.mask[base + before] = all;
+        out.z[base + before] = make_float4(ofp_u2f(z0), ofp_u2f(z1), ofp_u2f(z2), ofp_u2f(z3));
+    }
+}
+
+// a middle stage: lane = one distinct run, window offsets [p0, p1)
+__global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg(HpCand a, HpRuns runs, const int* __restrict__ n_runs,
+                                                             int64_t p0, int64_t p1) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *n_runs) return;
+    const HpArgs& st = a.st;
+    const int64_t grp = runs.grp[id];
+    const int64_t j = grp % st.n_chunks;
+    const int64_t chain = grp / st.n_chunks;
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    const float4 v = runs.z[id];
+    s.z[0] = v.x; s.z[1] = v.y; s.z[2] = v.z; s.z[3] = v.w;
+    const int64_t w0 = j * st.L - st.W;
+    hp_span<false>(st, s, chain, max<int64_t>(w0 + p0, 0), max<int64_t>(w0 + p1, 0));
+    runs.z[id] = make_float4(s.z[0], s.z[1], s.z[2], s.z[3]);
+}
+
+// the last stage: the chunk itself, with the records of every slot the run stands for
+__global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg_chunk(HpCand a, HpRuns runs, const int* __restrict__ n_runs) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *n_runs) return;
+    const HpArgs& st = a.st;
+    const int64_t grp = runs.grp[id];
+    const uint32_t mask = runs.mask[id];
+    const int64_t k = grp % st.n_chunks;
+    const int64_t chain = grp / st.n_chunks;
+    const int C = st.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    const float4 v = runs.z[id];
+    s.z[0] = v.x; s.z[1] = v.y; s.z[2] = v.z; s.z[3] = v.w;
+    const int64_t Ls = st.L / a.S;
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.g.V);
+    auto record = [&](int sb) {  // sb < 0: U, sb in [0, S-1): M, sb == S-1: E
+        for (uint32_t mm = mask; mm; mm &= mm - 1) {
+            const int slot = __ffs((int)mm) - 1;
+            uint32_t* dst = sb < 0 ? a.U + a.slot(clip, k, c, slot)
+                                   : (sb == a.S - 1 ? a.E + a.slot(clip, k, c, slot) : a.M + a.mslot(clip, k, c, slot, sb));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dst[w] = ofp_f2u(s.z[w]);
+        }
+    };
+    record(-1);
+#pragma unroll 1
+    for (int sb = 0; sb < a.S; ++sb) {
+        const int64_t t0 = min(start + sb * Ls, end);
+        const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
+        hp_span<false>(st, s, chain, t0, t1);
+        record(sb);
     }
 }
 
@@ -1061,8 +1222,10 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
                     first_stuck = i;
                 }
             }
-            if (redo)
+            if (redo) {
                 for (int sb = 0; sb < a.S; ++sb) a.done[ci * a.S + sb] = 0;
+                a.mrg[ci] = -1;
+            }
             if (sv < 0) {
                 v = STUCK;
                 break;
@@ -1109,13 +1272,14 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
         if (sp < 0) return;  // predecessor not resolved yet
     }
     const int own = a.sel[ci];
-    const bool whole = own < 0 || own >= a.R || a.guessed[ci];  // no exact inner states
+    const int mg = a.mrg[ci];  // >= 0: an earlier whole run joined candidate mg; its remaining sub-chunks are open
+    const bool whole = (own < 0 || own >= a.R || a.guessed[ci]) && mg < 0;  // no exact inner states
     if (whole && sb > 0) return;
     HpStep s;
     s.coeffs(st.b, st.a);
     uint32_t xin[4] = {0u, 0u, 0u, 0u};
     if (sb > 0) {
-        const uint32_t* m = a.M + a.mslot(clip, k, c, own, sb - 1);
+        const uint32_t* m = a.M + a.mslot(clip, k, c, mg >= 0 ? mg : own, sb - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xin[i] = m[i];
     } else if (k > 0) {
@@ -1128,9 +1292,41 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t start = k * st.L;
     const int64_t end = min(start + st.L, st.g.V);
     const int64_t Ls = st.L / a.S;
-    const int64_t t0 = whole ? start : min(start + sb * Ls, end);
-    const int64_t t1 = (whole || sb == a.S - 1) ? end : min(start + (sb + 1) * Ls, end);
-    hp_span<true>(st, s, chain, t0, t1);
+    if (!whole) {
+        const int64_t t0 = min(start + sb * Ls, end);
+        const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
+        hp_span<true>(st, s, chain, t0, t1);
+        if (sb == 0) a.ran[ci] = (int8_t)own;
+        a.done[ci * a.S + sb] = 1;
+        return;
+    }
+    // A whole run from the true start state.  With `early` it stops at the first sub-chunk boundary where its
+    // state equals (bitwise) the state some candidate recorded there: from that point on it IS that candidate's
+    // trajectory, so the chunk's end state is known at once (E of that candidate) and the sub-chunks behind the
+    // boundary are left to the lanes of the next round, which start from the candidate's inner states.
+    const int nq = a.early ? a.S : 1;
+    int joined = -1, n_done = a.S;
+#pragma unroll 1
+    for (int q = 0; q < nq; ++q) {
+        const int64_t t0 = nq == 1 ? start : min(start + q * Ls, end);
+        const int64_t t1 = (nq == 1 || q == nq - 1) ? end : min(start + (q + 1) * Ls, end);
+        hp_span<true>(st, s, chain, t0, t1);
+        if (q + 1 < nq) {
+            const uint32_t z0 = ofp_f2u(s.z[0]), z1 = ofp_f2u(s.z[1]), z2 = ofp_f2u(s.z[2]), z3 = ofp_f2u(s.z[3]);
+            for (int r = 0; r < a.R; ++r) {
+                if (a.U[a.slot(clip, k, c, r)] == 0x7fc00001u) continue;  // a slot no run filled: no records
+                const uint32_t* m = a.M + a.mslot(clip, k, c, r, q);
+                if (m[0] == z0 && m[1] == z1 && m[2] == z2 && m[3] == z3) {
+                    joined = r;
+                    break;
+                }
+            }
+            if (joined >= 0) {
+                n_done = q + 1;
+                break;
+            }
+        }
+    }
     if (own < 0 || a.guessed[ci]) {
         // no candidate matched: this exact run becomes slot R.  sel[ci] itself is NOT written
         // here (a successor running in this same launch must not see a half-filled slot); the
@@ -1138,19 +1334,17 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
         // compares it with the guess).
         uint32_t* u = a.U + a.slot(clip, k, c, a.R);
         uint32_t* e = a.E + a.slot(clip, k, c, a.R);
+        const uint32_t* ej = joined >= 0 ? a.E + a.slot(clip, k, c, joined) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u[i] = xin[i];
-            e[i] = ofp_f2u(s.z[i]);
+            e[i] = ej ? ej[i] : ofp_f2u(s.z[i]);
         }
     }
-    if (whole) {
-        a.ran[ci] = (int8_t)a.R;
-        for (int q = 0; q < a.S; ++q) a.done[ci * a.S + q] = 1;
-    } else {
-        if (sb == 0) a.ran[ci] = (int8_t)own;
-        a.done[ci * a.S + sb] = 1;
-    }
+    a.ran[ci] = (int8_t)a.R;
+    a.mrg[ci] = (int8_t)joined;
+    for (int q = 0; q < n_done; ++q) a.done[ci * a.S + q] = 1;
+    if (joined >= 0) atomicAdd(a.counters + 1, 1);  // open sub-chunks: the host must enqueue another round
 }
 
 // ---- elementwise stages (planar, in place) -------------------------------------------
@@ -1661,12 +1855,14 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R, hp_S, hp_span;
+    bool hp_early;   // whole runs stop early at a sub-chunk boundary (k_hp_run)
+    bool hp_staged;  // candidates in stages with duplicate runs removed between them (k_hp_seg*)
     int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks, ar_S;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks, mm_S;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, o_zero, zero_bytes, total;
 };
 
@@ -1723,7 +1919,24 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     if (d->t.hp_span <= 0 && l.hp_R % 2 == 0 &&
         chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * cus)
         l.hp_span = 2;
-    l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;  // sub-chunks run in parallel once a chunk's start is verified
+    // Staged candidates with duplicates removed (k_hp_seg0 / k_hp_dedupe / k_hp_seg / k_hp_seg_chunk): a third of
+    // the steps in six launches instead of one -- for launches that are throughput-bound (the same condition as
+    // the automatic span 2, which it replaces: every chunk then has its own R candidates again).
+    // hp_dedupe: 0 auto, 1 always, < 0 never.
+    {
+        const bool busy = chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * cus;
+        l.hp_staged = d->t.hp_dedupe > 0 || (d->t.hp_dedupe == 0 && d->t.hp_span <= 0 && busy);
+        if (l.hp_W < 8192 || l.hp_R < 2) l.hp_staged = false;
+        if (l.hp_staged) l.hp_span = 1;
+    }
+    // sub-chunks: run in parallel once a chunk's start is verified (every candidate records its state at the inner
+    // boundaries).  Long chunks (batches) get more of them, about 4096 samples each, and their whole runs from a
+    // true start state stop at the first boundary where they have joined a candidate (k_hp_run, `early`): a break
+    // then costs a few thousand sequential steps instead of the 32-64 k of the chunk.
+    l.hp_S = (l.hp_L % (4 * 64) == 0) ? 4 : 1;
+    if (l.hp_L >= 32768 && l.hp_L % (16 * 64) == 0) l.hp_S = (int)std::min<int64_t>(16, l.hp_L / 4096);
+    l.hp_early = l.hp_S > 1 && l.hp_L / l.hp_S >= 4096 && d->t.hp_early >= 0;
+    if (d->t.hp_early > 0 && l.hp_S > 1) l.hp_early = true;
     l.ar_L = pick(d->t.ar_chunk, arL);
     l.ar_W = pick_warm(d->t.ar_warm, align_up((int64_t)std::min(10.0 * tau, 4.0e6), 1024));
     l.ar_Wc = pick_warm(d->t.ar_coarse_warm, align_up((int64_t)std::min(14.0 * tau, 8.0e6), 1024));
@@ -1794,6 +2007,10 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         l.o_hp_guess = take(cc);
         l.o_hp_ran = take(cc);
         l.o_hp_gs = take(cc);
+        l.o_hp_mrg = take(cc);
+        // staged candidates: two work lists of {group, slot set, state} and the groups' ranges in the current one
+        l.o_hp_runs = take(l.hp_staged ? 2 * cc * l.hp_R * 24 + 64 : 0);
+        l.o_hp_goff = take(l.hp_staged ? 2 * cc * 4 : 0);
     }
     l.o_ar_state = take(3 * n_clips * l.ar_chunks * g.C * 2 * 4);
     l.o_ar_P = take(n_clips * l.ar_chunks * g.C * 8);
@@ -1810,6 +2027,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_flags = take(OFP_N_COUNTERS * 4);  // pass / round counters, one fresh slot per use
     l.o_zero = l.o_flags;
     l.o_hp_pos = take(n_clips * g.C * 4);
+    l.o_hp_stage_n = take(16 * 4);  // runs left after each dedupe of the staged candidates
     l.o_mm_dirty = take(n_clips * l.mm_chunks * g.C);
     l.o_vflag = take(n_clips * l.nb * 4);
     l.zero_bytes = o - l.o_zero;
@@ -1938,7 +2156,7 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
     for (int k = 0; k < 10 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_flags, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_flags, 256, hipHostMallocDefault);
     if (e == hipSuccess) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -2081,6 +2299,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.guessed = reinterpret_cast<uint8_t*>(ws + l.o_hp_guess);
         hc.ran = reinterpret_cast<int8_t*>(ws + l.o_hp_ran);
         hc.gs = reinterpret_cast<int8_t*>(ws + l.o_hp_gs);
+        hc.mrg = reinterpret_cast<int8_t*>(ws + l.o_hp_mrg);
+        hc.early = l.hp_early ? 1 : 0;
         hc.counters = ctr.base;
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         hc.probe = nullptr;
@@ -2092,7 +2312,49 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const int64_t nM = chains * l.hp_chunks * (hc.R + 1);
         const int64_t nC = chains * l.hp_chunks * l.hp_S;
         const int64_t nC0 = chains * l.hp_chunks;
-        if (do_cand) {
+        // staged candidates: window offsets at which duplicates are removed (the last one is the chunk start)
+        int64_t cuts[16];
+        int n_cuts = 0;
+        if (l.hp_staged) {
+            // (the runs of a group merge fastest early on: 8 -> 4.8 distinct within 8 192 steps, -> 2.2 by 24 576)
+            for (int64_t c = 4096; c < l.hp_W && n_cuts < 15; c += (c < 8192 ? 4096 : (c < 40960 ? 8192 : 16384)))
+                cuts[n_cuts++] = c;
+            cuts[n_cuts++] = l.hp_W;
+        }
+        int* stage_n = reinterpret_cast<int*>(ws + l.o_hp_stage_n);
+        if (do_cand && l.hp_staged) {
+            const int64_t n0 = nC0 * hc.R;
+            OFP_REQUIRE(n0 < (1ll << 31), "ofp_detect_offline: %lld speculative runs in one call", (long long)n0);
+            HpRuns rl[2];
+            // layout of the two lists: z (16 B) of both first, then grp, then mask
+            unsigned char* rb = ws + l.o_hp_runs;
+            rl[0].z = reinterpret_cast<float4*>(rb);
+            rl[1].z = reinterpret_cast<float4*>(rb + n0 * 16);
+            rl[0].grp = reinterpret_cast<int32_t*>(rb + n0 * 32);
+            rl[1].grp = reinterpret_cast<int32_t*>(rb + n0 * 36);
+            rl[0].mask = reinterpret_cast<uint32_t*>(rb + n0 * 40);
+            rl[1].mask = reinterpret_cast<uint32_t*>(rb + n0 * 44);
+            int32_t* goff = reinterpret_cast<int32_t*>(ws + l.o_hp_goff);
+            int32_t* gcnt = goff + nC0;
+            const unsigned full_grid = (unsigned)cdiv(n0, HP_CAND_THREADS);
+            hipLaunchKernelGGL(k_hp_seg0, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[0], goff, gcnt, cuts[0], n0);
+            OFP_LAUNCH_CHECK("k_hp_seg0");
+            int cur = 0;
+            for (int m = 0; m < n_cuts; ++m) {
+                hipLaunchKernelGGL(k_hp_dedupe, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, rl[cur], rl[cur ^ 1],
+                                   goff, gcnt, nC0, stage_n + m);
+                cur ^= 1;
+                // (the grid is sized for the worst case, every run distinct; the lanes beyond the list leave at once)
+                if (m + 1 < n_cuts)
+                    hipLaunchKernelGGL(k_hp_seg, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
+                                       (const int*)(stage_n + m), cuts[m], cuts[m + 1]);
+                else
+                    hipLaunchKernelGGL(k_hp_seg_chunk, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
+                                       (const int*)(stage_n + m));
+            }
+            OFP_LAUNCH_CHECK("k_hp_dedupe / k_hp_seg / k_hp_seg_chunk");
+            OFP_HIP(hipEventRecord(ev[7], stream));
+        } else if (do_cand) {
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
             if ((int64_t)cand_grid <= d->n_cus && d->t.concurrent_calls <= 1)
                 hipLaunchKernelGGL(k_hp_candidates<true>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
@@ -2114,7 +2376,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             }
         }
         hp_cand_timed = true;
-        {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
+        if (l.hp_staged) {  // stage 0 here; the later stages once their run counts are on the host (below)
+            int64_t steps = 0;
+            for (int64_t j = 0; j < l.hp_chunks; ++j)
+                for (int r = 0; r < hc.R; ++r)
+                    steps += std::max<int64_t>(j * l.hp_L - l.hp_W + cuts[0], 0) -
+                             std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
+            info[12] = steps * chains;
+        } else {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
             int64_t steps = 0;
             const int Rm = hc.R / hc.span;
             for (int64_t j = 0; j < l.hp_chunks; ++j) {
@@ -2129,6 +2398,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         OFP_LAUNCH_CHECK("k_hp_plurality");
         // Verification rounds are enqueued a group at a time (three, then two) with ONE host synchronisation
         // per group; a round whose predecessor left nothing unresolved returns at once (HpCand::prev).
+        if (l.hp_staged)
+            OFP_HIP(hipMemcpyAsync(d->h_flags + 16, stage_n, 16 * sizeof(int), hipMemcpyDeviceToHost, stream));
         const int* last = nullptr;
         for (int it = 0;;) {
             const int G = d->t.verify_group > 0 ? (int)std::min<int64_t>(d->t.verify_group, 8) : (it == 0 ? 3 : 2);
@@ -2160,6 +2431,12 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             if (stuck == 0) break;
             if (d->t.max_passes > 0 && it > d->t.max_passes)
                 return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
+        }
+        if (l.hp_staged) {  // distinct runs that walked each later segment / the chunk (slightly over: clamped windows)
+            const int* n = d->h_flags + 16;
+            for (int m = 0; m + 1 < n_cuts; ++m) info[12] += (int64_t)n[m] * (cuts[m + 1] - cuts[m]);
+            info[12] += (int64_t)n[n_cuts - 1] * l.hp_L;
+            info[13] = n[n_cuts - 1];  // runs that walked a chunk (of chains * chunks * R candidates)
         }
     }
     if (phase == 1 || phase == 6) return OFP_OK;  // (no high-pass: the head is the transpose alone)

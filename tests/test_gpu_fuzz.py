@@ -55,6 +55,8 @@ def random_case(rng):
         tuning["hp_candidates"] = int(rng.choice([1, 2, 4, 8, 16]))
         tuning["hp_span"] = int(rng.choice([1, 2, 4]))
         tuning["hp_candidate_offset"] = int(rng.choice([-1, 1, 8, 1021]))
+        tuning["hp_dedupe"] = int(rng.choice([-1, 0, 1, 1]))  # staged candidates (the batch setting) on small inputs too
+        tuning["hp_early"] = int(rng.choice([-1, 0, 1, 1]))   # early stop of whole re-runs
     if rng.random() < 0.5:
         tuning["ar_chunk"] = int(rng.choice([512, 1024, 4096]))
         tuning["ar_warm"] = int(rng.choice([1024, 8192, 24576]))

@@ -74,6 +74,14 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(hp_chunk=4096, hp_warm=16384, hp_candidates=3, ar_chunk=8192, ar_warm=30000, mm_chunk=4096, mm_warm=20000),
                    dict(hp_chunk=50000, hp_candidates=1, ar_chunk=100000, ar_coarse_warm=-1, mm_chunk=30000, mm_warm=100000),
                    dict(concurrent_calls=8),   # the layout of a call that has an eighth of the GPU
+                   dict(hp_dedupe=1),          # staged candidates with duplicate runs removed (the batch setting)
+                   dict(hp_dedupe=1, hp_chunk=4096, hp_warm=20000, hp_candidates=5),
+                   dict(hp_dedupe=1, hp_candidates=16, hp_candidate_offset=-1),
+                   dict(hp_dedupe=-1, concurrent_calls=8),
+                   dict(hp_early=1),           # whole re-runs that stop where they join a candidate
+                   dict(hp_early=1, hp_candidates=2, hp_warm=6000, hp_chunk=4096),   # many breaks
+                   dict(hp_early=1, hp_dedupe=1, hp_candidates=3, hp_warm=9000, hp_chunk=32768),
+                   dict(hp_early=-1, hp_dedupe=1, hp_chunk=32768),
                    dict(concurrent_calls=64),
                    None):
         bd = detection.BatchDetector(8, 256, sr=SR)

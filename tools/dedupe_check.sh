@@ -1,0 +1,21 @@
+#!/bin/bash
+# staged IIR candidates: parity tests, then throughput with and without -> gpurun_out/dedupe_check.log
+set -e
+mkdir -p gpurun_out
+L=gpurun_out/dedupe_check.log
+: > $L
+timeout -k 10 600 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_detect.py tests/test_gpu_fuzz.py -x -q -m gpu >> $L 2>&1
+run() { echo "== $*" >> $L; timeout -k 10 300 python bench.py --no-cpu --no-extras --steps 24 --warmup 8 "$@" 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j = json.loads(l); print(round(j['value'] / 1e6, 1), 'M frames/s', round(j['ms_per_step'], 3), 'ms/step', j['config'].get('steps_in_flight_per_gpu'), j['config'].get('detector_tuning'), json.dumps(j.get('stage_ms')), j['roofline'].get('issue', {}).get('flop_per_launch'))
+" >> $L; }
+for dd in -1 0; do
+run --workload c2 --clips 16 --inflight 4 --tuning "{\"hp_dedupe\": $dd}"
+run --workload c2 --clips 16 --inflight 1 --tuning "{\"hp_dedupe\": $dd}"
+run --workload c4 --inflight 4 --tuning "{\"hp_dedupe\": $dd}"
+run --workload c4 --inflight 1 --tuning "{\"hp_dedupe\": $dd}"
+run --workload c4 --shard-of 8 --inflight 12 --tuning "{\"hp_dedupe\": $dd, \"concurrent_calls\": 4}"
+done
+tail -30 $L
