@@ -128,6 +128,10 @@ typedef struct ofp_detect_tuning {
     int64_t hp_early;            /* IIR stage: a chunk re-run whole from its true start state stops at the first
                                     sub-chunk boundary where it has joined a candidate's recorded trajectory:
                                     0 auto (chunks of 32768 samples and more), 1 always, < 0 never */
+    int64_t lane_merge;          /* follower / tracker stage: the two recurrences of a chunk (fast / slow follower,
+                                    min / max) in one lane instead of two: half the reads of those passes, a longer
+                                    dependent chain per lane: more frames/s when calls overlap, a slower lone call.
+                                    0 auto (on when concurrent_calls >= 2), 1 always, < 0 never */
     int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
                                     at once (0 / 1: this call has the GPU to itself).  The layout of the
                                     speculative passes is chosen for the GPU's share: with k calls in flight each

@@ -59,6 +59,7 @@ class DetectTuning(ctypes.Structure):
         ("verify_group", ctypes.c_int64),
         ("hp_dedupe", ctypes.c_int64),
         ("hp_early", ctypes.c_int64),
+        ("lane_merge", ctypes.c_int64),
         ("concurrent_calls", ctypes.c_int64),
     ]
 

@@ -517,6 +517,34 @@ __global__ __launch_bounds__(64) void k_ar_warm2(ArArgs a, int64_t n_threads, ui
     }
 }
 
+// k_ar_warm2 with both followers in ONE lane (throughput setting): a saturated launch pays for bytes, not for the
+// length of a lane's dependent chain, and the two lanes of a chunk read the same samples at different times (the
+// slow one W ahead of the chunk, the fast one Wf), so each line of the stream came from HBM twice.  Here the
+// fast follower simply starts with the slow one (a longer warm-up than it needs).
+__global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t n_groups = cdiv(a.n_chunks, a.S);
+    const int64_t g = id % n_groups;
+    const int64_t chain = id / n_groups;
+    const int64_t k0 = g * a.S;
+    const int64_t start = k0 * a.L;
+    const float* xs = a.xdb + chain * a.g.U;
+    int norem = -1;
+    const int64_t ws = max<int64_t>(start - a.W, 0);
+    const int64_t s0 = (chain * a.n_chunks + k0) * 2;
+    ArStep s{a.floor_db, ofp_u2f(used[s0 + 1]), a.fa, a.fr, a.sa, a.sr};  // floor / closed-form guess at the run's start
+    walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
+    used[s0] = ofp_f2u(s.yf);
+    used[s0 + 1] = ofp_f2u(s.ys);
+    for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+        walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
+        used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.yf);
+        used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.ys);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_threads,
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
@@ -678,6 +706,87 @@ __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_t
         walk<8, 0, true>(rs, nullptr, end - start, rem, s);
         end_next[sidx] = ofp_f2u(s.mx);
     }
+}
+
+// The same two kernels with the min and the max in ONE lane (MmStep, the 2-wide packed step): the throughput
+// setting.  A saturated launch pays for the bytes it moves, and the separate lanes read every line of the stream
+// twice, at different times; the pair costs no more instructions than the two one-word walks together.
+__global__ __launch_bounds__(64) void k_mm_warm_both(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t n_groups = cdiv(a.n_chunks, a.S);
+    const int64_t g = id % n_groups;
+    const int64_t chain = id / n_groups;
+    const int64_t k0 = g * a.S;
+    const int64_t start = k0 * a.L;
+    const float* rs = a.rel + chain * a.g.U;
+    int norem = -1;
+    const int64_t ws = max<int64_t>(start - a.W, 0);
+    // max guessed from below, min from above (see k_mm_warm2); exact when the window reaches the stream start
+    MmStep s{ws > 0 ? __builtin_inff() : a.min0, ws > 0 ? 0.0f : a.max0, a.minmin, v2f{a.ialpha_min, a.ialpha_max},
+             v2f{a.alpha_min, a.alpha_max}, nullptr, nullptr, 0, 0, nullptr};
+    walk<8, 0, false>(rs + ws, nullptr, start - ws, norem, s);
+    used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(s.mn);
+    used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(s.mx);
+    for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+        walk<8, 0, false>(rs + (k - 1) * a.L, nullptr, a.L, norem, s);
+        used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.mn);
+        used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.mx);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mm_chunk_both(MmArgs a, int pass, int64_t n_threads,
+                                                      const uint32_t* __restrict__ end_prev,
+                                                      uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                      int* changed) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t k = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t start = k * a.L;
+    const int64_t end = min(start + a.L, a.g.U);
+    const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    uint32_t i0 = used[sidx], i1 = used[sidx + 1];
+    if (pass > 0) {
+        if (k == 0) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
+        const bool redo = a.dirty[id] != 0;  // a light pass changed this chunk's starting max
+        if (p0 == i0 && p1 == i1 && !redo) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        a.dirty[id] = 0;
+        i0 = p0;
+        i1 = p1;
+        used[sidx] = i0;
+        used[sidx + 1] = i1;
+        atomicAdd(changed, 1);
+    }
+    const int C = a.g.C;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
+    int rem;
+    const int64_t m = start - a.g.n_wb;  // position in the main part (negative: still warm part)
+    int64_t j = 0;
+    if (m >= 0) {
+        j = m / a.g.B;
+        rem = (int)(a.g.B - 1 - (m - j * a.g.B));
+    } else {
+        rem = (int)min<int64_t>(-m + a.g.B - 1, 0x7fffffff);
+    }
+    const int64_t oi = (clip * a.nb + j) * C + c;
+    MmStep s{ofp_u2f(i0), ofp_u2f(i1), a.minmin, v2f{a.ialpha_min, a.ialpha_max}, v2f{a.alpha_min, a.alpha_max},
+             a.thr_mn + oi, a.thr_mx + oi, C, a.g.B, &rem};
+    walk<8, 0, true>(a.rel + chain * a.g.U + start, nullptr, end - start, rem, s);
+    end_next[sidx] = ofp_f2u(s.mn);
+    end_next[sidx + 1] = ofp_f2u(s.mx);
 }
 
 // The max coalesces only where the true max is reset, so a stretch without a reset (a loud hit
@@ -1855,6 +1964,7 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R, hp_S, hp_span;
+    bool merge;      // followers / tracker: the two recurrences of a chunk in one lane (k_*_both; saturated launches)
     bool hp_early;   // whole runs stop early at a sub-chunk boundary (k_hp_run)
     bool hp_staged;  // candidates in stages with duplicate runs removed between them (k_hp_seg*)
     int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks, ar_S;
@@ -1984,6 +2094,13 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
             if (t[i] <= 1.10 * best && cand[i] <= std::max<int64_t>(n_chunks, 1)) S = cand[i];
         return S;
     };
+    // Saturated launches (more than two waves per SIMD of this call's share): the fast / slow follower and the
+    // tracker's min / max walk as ONE lane per chunk -- each line of the stream is then read once per pass instead of
+    // twice at different times.  lane_merge: 0 auto, 1 always, < 0 never.
+    // (measured, 16 x C2 / 512 x C4: four calls in flight +10 % / +5 % frames/s; ONE call at a time 11 % / 7 % slower --
+    //  even a 2048-chain call is bound by its lanes' chains, not by bytes, when it has the GPU to itself: so auto
+    //  means "the caller said that calls overlap", concurrent_calls >= 2)
+    l.merge = d->t.lane_merge > 0 || (d->t.lane_merge == 0 && d->t.concurrent_calls >= 2);
     l.ar_S = l.ar_sym ? pick_span(d->t.ar_span, l.ar_W, l.ar_L, l.ar_chunks, 16.0) : 1;
     l.mm_S = pick_span(d->t.mm_span, l.mm_W, l.mm_L, l.mm_chunks, 11.0);
     l.tu = (int)std::max<int64_t>(1, std::min<int64_t>(256, 8192 / g.C));
@@ -2479,7 +2596,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
         if (l.ar_sym) {
             const int64_t ntg = chains * cdiv(l.ar_chunks, l.ar_S);  // one run per group of S chunks
-            hipLaunchKernelGGL(k_ar_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            if (l.merge)
+                hipLaunchKernelGGL(k_ar_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            else
+                hipLaunchKernelGGL(k_ar_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_ar_warm2");
         } else {
             hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
@@ -2524,10 +2644,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const unsigned grid = (unsigned)cdiv(nt, 64);
         {
             const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
-            hipLaunchKernelGGL(k_mm_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            if (l.merge)
+                hipLaunchKernelGGL(k_mm_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            else
+                hipLaunchKernelGGL(k_mm_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_mm_warm2");
         }
-        int rc = run_jacobi("tracker stage", k_mm_chunk, a, 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, ctr, d->h_flags,
+        int rc = run_jacobi("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a, l.merge ? nt : 2 * 64 * cdiv(nt, 64),
+                            l.mm_chunks, used, ctr, d->h_flags,
                             d->t.max_passes, d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &info[2], &info[3],
                             +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch,
                                 hipStream_t st) {

@@ -64,6 +64,8 @@ def random_case(rng):
     if rng.random() < 0.5:
         tuning["mm_chunk"] = int(rng.choice([1024, 4096, 8192]))
         tuning["mm_warm"] = int(rng.choice([0, 4096, 49152])) or -1
+    if rng.random() < 0.4:
+        tuning["lane_merge"] = int(rng.choice([-1, 1]))
     return x, kw, tuning
 
 
