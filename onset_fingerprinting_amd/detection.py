@@ -207,7 +207,9 @@ class BatchDetector:
             stage_ms=dict(hp=info[4] / 1e6, db=info[5] / 1e6, ar=info[6] / 1e6, rel=info[7] / 1e6,
                           mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6,
                           hp_candidates=info[11] / 1e6),
-            hp_candidate_steps=info[12])
+            hp_candidate_steps=info[12],
+            # staged candidates only (0 otherwise): distinct runs that walked a chunk
+            hp_chunk_runs=info[13])
         out["cap"] = cap
         return out
 
