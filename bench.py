@@ -290,6 +290,7 @@ def main():
         # steps overlap: the detector's throughput setting (fast/slow follower and min/max as one lane per chunk:
         # half the reads of those passes; 16 x C2, four in flight: 116 -> 127 M frames/s; a lone call is slower with it)
         auto_tuning["lane_merge"] = 1
+        auto_tuning["hp_dedupe"] = 1   # IIR candidates in stages, duplicate runs removed (a third of the speculative steps)
     if workload == "c4" and n_local <= 128 and D >= 4:
         # small shards, many calls in flight: each call lays its speculative passes out for a quarter of the
         # GPU instead of as if it were alone (ofp_detect_tuning.concurrent_calls; results do not change)

@@ -124,7 +124,8 @@ typedef struct ofp_detect_tuning {
                                     1: one host round trip per pass, the round-1 behaviour) */
     int64_t hp_dedupe;           /* IIR stage: speculative candidates in stages with duplicate runs removed between
                                     them (a third of the steps, six launches instead of one): 0 auto (batches whose
-                                    candidate launch is throughput-bound), 1 always, < 0 never */
+                                    candidate launch is throughput-bound, when concurrent_calls >= 2), 1 always,
+                                    < 0 never */
     int64_t hp_early;            /* IIR stage: a chunk re-run whole from its true start state stops at the first
                                     sub-chunk boundary where it has joined a candidate's recorded trajectory:
                                     0 auto (chunks of 32768 samples and more), 1 always, < 0 never */
@@ -193,6 +194,16 @@ int ofp_detect_offline_begin_input(ofp_detector* det, const float* d_x, int64_t 
                                    int64_t warm, void* d_ws, int64_t ws_bytes, void* stream);
 int ofp_detect_offline_begin_iir(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                                  int64_t warm, void* d_ws, int64_t ws_bytes, void* stream);
+/* Collation block of a rank (the all-gather of onset indices): the onset records of a batch of
+ * clips, d_records [n_clips][cap_per_clip] with d_counts [n_clips] as ofp_detect_offline leaves them, compacted
+ * in clip order into d_block [1 + cap_total] without a host round trip (no data-dependent shape).  Record 0 is
+ * the header {clip: 0, channel: 1 if some clip counted more onsets than cap_per_clip (lost records), sample:
+ * total number of records}; records 1.. follow with clip_offset added to their clip ids; records that do not
+ * fit cap_total are dropped (the header still carries the true total, so the reader can tell); rows beyond
+ * the total are not written.  One launch. */
+int ofp_pack_records(const ofp_onset* d_records, const int64_t* d_counts, int64_t n_clips, int64_t cap_per_clip,
+                     int64_t cap_total, int32_t clip_offset, ofp_onset* d_block, void* stream);
+
 /* Streaming form: AmplitudeOnsetDetector.__call__ (detection.py:727-798) on
  * n_blocks consecutive blocks with the detector state carried in d_state
  * (ofp_stream_state_bytes() bytes, initialised by ofp_stream_state_init).

@@ -106,6 +106,7 @@ SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_vp)]),
     "ofp_detector_destroy": (ctypes.c_int, [_vp]),
     "ofp_detector_set_tuning": (ctypes.c_int, [_vp, ctypes.POINTER(DetectTuning)]),
+    "ofp_pack_records": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp]),
     "ofp_detect_workspace_bytes": (_i64, [_vp, _i64, _i64, _i64]),
     "ofp_detect_offline": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
                                           ctypes.POINTER(_i64), _vp]),

@@ -849,7 +849,11 @@ __device__ __forceinline__ void hp_span(const HpArgs& a, F& f, int64_t chain, in
         const int64_t e = min(max(br, p), t1);
         if (e > p) {
             const int64_t u = hp_dst(a.g, p);
-            if (u >= 0) walk<8, 1, false>(xs + p, os + u, e - p, norem, f);
+            // 16-byte stores whenever the output is congruent to the input modulo 16 bytes (it is for every block
+            // size and warm-up length that are multiples of 4 samples): a quarter of the store instructions
+            if (u >= 0 && ((reinterpret_cast<uintptr_t>(xs + p) ^ reinterpret_cast<uintptr_t>(os + u)) & 15u) == 0)
+                walk<8, 4, false>(xs + p, os + u, e - p, norem, f);
+            else if (u >= 0) walk<8, 1, false>(xs + p, os + u, e - p, norem, f);
             else walk<8, 0, false>(xs + p, nullptr, e - p, norem, f);
         }
         p = e;
@@ -2035,7 +2039,10 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     // hp_dedupe: 0 auto, 1 always, < 0 never.
     {
         const bool busy = chains * cdiv(g.V, pick(d->t.hp_chunk, hpL)) * l.hp_R > (int64_t)64 * 4 * cus;
-        l.hp_staged = d->t.hp_dedupe > 0 || (d->t.hp_dedupe == 0 && d->t.hp_span <= 0 && busy);
+        // (auto = the caller said that calls overlap: in flight the stages are +4-5 % frames/s; for ONE call at a time they
+        //  are no faster, and slower beside the STFT launch that shares the GPU with them -- C3 at full size 75.6
+        //  against 72.2 ms)
+        l.hp_staged = d->t.hp_dedupe > 0 || (d->t.hp_dedupe == 0 && d->t.hp_span <= 0 && busy && d->t.concurrent_calls >= 2);
         if (l.hp_W < 8192 || l.hp_R < 2) l.hp_staged = false;
         if (l.hp_staged) l.hp_span = 1;
     }

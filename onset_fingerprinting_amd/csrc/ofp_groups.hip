@@ -215,6 +215,62 @@ __global__ __launch_bounds__(G_THREADS) void k_group_windows(const float* __rest
     }
 }
 
+
+// ---- collation block: the records of all clips of a rank, compacted in clip order behind a header.
+// One workgroup per clip: its first output row = 1 + the (clamped) counts of the clips before it, summed by the
+// workgroup itself (at most 65535 clips: a few hundred loads per lane); workgroup 0 also writes the header.
+__global__ __launch_bounds__(256) void k_pack_records(const ofp_onset* __restrict__ rec, const int64_t* __restrict__ counts,
+                                                      int64_t n_clips, int64_t cap, int64_t cap_total, int32_t clip_offset,
+                                                      ofp_onset* __restrict__ block) {
+    __shared__ long long s_part[G_WAVES];
+    __shared__ int s_over[G_WAVES];
+    const int64_t clip = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t upto = clip == 0 ? n_clips : clip;  // workgroup 0 sums everything (the total)
+    long long acc = 0;
+    int over = 0;
+    for (int64_t i = threadIdx.x; i < upto; i += G_THREADS) {
+        const int64_t c = counts[i];
+        acc += (long long)min<int64_t>(max<int64_t>(c, 0), cap);
+        over |= c > cap;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        over |= __shfl_xor(over, o);
+    }
+    if (lane == 0) {
+        s_part[wave] = acc;
+        s_over[wave] = over;
+    }
+    __syncthreads();
+    acc = 0;
+    over = 0;
+    for (int w = 0; w < G_WAVES; ++w) {
+        acc += s_part[w];
+        over |= s_over[w];
+    }
+    int64_t first = 1 + acc;
+    if (clip == 0) {
+        first = 1;
+        if (threadIdx.x == 0) {
+            ofp_onset h;
+            h.clip = 0;
+            h.channel = over ? 1 : 0;
+            h.sample = acc;
+            block[0] = h;
+        }
+    }
+    const int64_t n = min<int64_t>(max<int64_t>(counts[clip], 0), cap);
+    const ofp_onset* src = rec + clip * cap;
+    for (int64_t k = threadIdx.x; k < n; k += G_THREADS) {
+        const int64_t row = first + k;
+        if (row > cap_total) break;  // does not fit: dropped, the header tells
+        ofp_onset o = src[k];
+        o.clip += clip_offset;
+        block[row] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,6 +322,17 @@ int ofp_group_windows(const float* d_x, int64_t n_clips, int64_t n_samples, int3
                        d_groups, cap_groups, d_n_groups, pre_samples, use_min_onset, width, d_out, cap_total,
                        (const int64_t*)d_offsets);
     OFP_LAUNCH_CHECK("k_group_windows");
+    return OFP_OK;
+}
+
+int ofp_pack_records(const ofp_onset* d_records, const int64_t* d_counts, int64_t n_clips, int64_t cap_per_clip,
+                     int64_t cap_total, int32_t clip_offset, ofp_onset* d_block, void* stream) {
+    OFP_REQUIRE(d_counts && d_block && n_clips >= 1 && n_clips <= 65535 && cap_per_clip >= 0 && cap_total >= 0,
+                "ofp_pack_records: bad argument");
+    OFP_REQUIRE(d_records || cap_per_clip == 0, "ofp_pack_records: d_records is NULL");
+    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)n_clips), dim3(G_THREADS), 0, (hipStream_t)stream, d_records, d_counts,
+                       n_clips, cap_per_clip, cap_total, clip_offset, d_block);
+    OFP_LAUNCH_CHECK("k_pack_records");
     return OFP_OK;
 }
 

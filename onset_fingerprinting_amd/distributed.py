@@ -82,6 +82,18 @@ def pack_clips(records, counts, cap_total, clip_offset=0):
     order with `clip_offset` added to their clip ids; rows beyond the count are don't-care."""
     n_clips, cap = records.shape[0], records.shape[1]
     dev = records.device
+    if records.is_cuda:
+        # one launch (ofp_pack_records) instead of a dozen small tensor operations; rows beyond the count stay
+        # unwritten (don't-care for `unpack_gathered`)
+        from . import _lib
+        from .detection import _stream_ptr
+        records = records.contiguous()
+        counts = counts.to(device=dev, dtype=torch.int64).contiguous()
+        block = torch.empty((cap_total + 1, 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ofp_pack_records(records.data_ptr(), counts.data_ptr(), n_clips, cap, int(cap_total),
+                                                   int(clip_offset), block.data_ptr(), _stream_ptr(dev)), "ofp_pack_records")
+        return block
     c = counts.to(torch.int64).clamp(max=cap)
     offs = torch.cumsum(c, 0) - c                                   # first output row of each clip
     k = torch.arange(cap, device=dev, dtype=torch.int64)[None, :]

@@ -236,3 +236,27 @@ def test_pipelines_in_flight_from_several_threads_give_the_same_bytes():
         for got in results[i]:
             for a, b in zip(alone[i], got):
                 assert a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_collation_block_kernel_equals_the_tensor_form():
+    """ofp_pack_records (one launch) against the device-independent tensor form of `pack_clips` (the one the gloo
+    tests run on the CPU): header, order, clip offset, overflow flag, records that do not fit."""
+    from onset_fingerprinting_amd.distributed import all_gather_blocks, flatten_records, pack_clips, unpack_gathered
+    rng = np.random.default_rng(5)
+    for n_clips, cap, cap_total, off in ((5, 8, 32, 10), (1, 4, 4, 0), (300, 16, 2000, 7), (64, 3, 50, 0)):
+        rec = np.zeros((n_clips, cap), dtype=np.dtype([("clip", np.int32), ("channel", np.int32), ("sample", np.int64)]))
+        rec["clip"] = np.arange(n_clips)[:, None]
+        rec["channel"] = rng.integers(0, 8, (n_clips, cap))
+        rec["sample"] = rng.integers(0, 1 << 40, (n_clips, cap))
+        r8 = torch.from_numpy(rec.view(np.uint8).reshape(n_clips, cap, 16).copy())
+        counts = torch.from_numpy(rng.integers(0, cap + 1, n_clips).astype(np.int64))
+        if n_clips == 64:
+            counts[3] = cap + 2  # a clip that lost records: flagged in the header
+        want = pack_clips(r8, counts, cap_total, clip_offset=off)          # CPU tensors: the tensor form
+        got = pack_clips(r8.cuda(), counts.cuda(), cap_total, clip_offset=off).cpu()   # ofp_pack_records
+        total = int(counts.clamp(max=cap).sum())
+        n = 1 + min(total, cap_total)
+        assert torch.equal(got[:n], want[:n]), (n_clips, cap, cap_total)
+        if total <= cap_total and n_clips != 64:
+            assert torch.equal(unpack_gathered(all_gather_blocks(got)), flatten_records(r8, counts, cap) if off == 0 else
+                               unpack_gathered(all_gather_blocks(want)))
