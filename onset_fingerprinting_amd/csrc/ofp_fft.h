@@ -111,8 +111,11 @@ __device__ __forceinline__ constexpr int fft_pad_step(int Ns, int i) {
     return M > 512 ? i * Ns : (Ns == 1 ? i : (Ns == 8 ? 8 * i + (i >> 1) : i * (Ns + (Ns >> 4))));
 }
 
-template <int R, int M, int T>
-__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid) {
+// FROM_REGS: the inputs of the pass are handed over in registers (`in[b * R + i]` = point tid + b T + i M/R): the
+// first pass of a frame whose lanes have just formed exactly those points (windowed samples) -- the frame never
+// makes the round trip through the buffer before its first butterfly.
+template <int R, int M, int T, bool FROM_REGS = false>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, int tid, const float2* in = nullptr) {
     constexpr int NB = (M / R) / T;  // butterflies per lane (1 for radix 8, 2 for radix 4)
     static_assert((M / R) % T == 0 && NB >= 1, "lanes per frame must divide the butterflies of a pass");
     static_assert((M / R) % 16 == 0, "the read stride of a pass must be a multiple of the pad period");
@@ -122,9 +125,10 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int Ns, 
         const int j = tid + b * T;
         const float2* src = buf + fft_pad<M>(j);
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[b][i] = src[i * ((M / R) + (M <= 512 ? (M / R) / 16 : 0))];
+        for (int i = 0; i < R; ++i)
+            v[b][i] = FROM_REGS ? in[b * R + i] : src[i * ((M / R) + (M <= 512 ? (M / R) / 16 : 0))];
     }
-    frame_sync<T>();  // all reads of this pass are done
+    frame_sync<T>();  // all reads of this pass are done (FROM_REGS: the previous user of the buffer is done with it)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
@@ -158,6 +162,28 @@ __device__ __forceinline__ void cfft(float2* a, const float2* tw, int tid) {
     frame_sync<T>();  // the frame has been written
 #pragma unroll
     for (int p = 0; p < Rx::n; ++p) {
+        if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
+        else fft_pass<4, M, T>(a, tw, Ns, tid);
+        Ns *= Rx::r[p];
+    }
+}
+
+// The same transform with the input in registers: lane tid holds the points tid + q T, q < M / T, in `in[q]`
+// (the order the first radix-8 pass wants them in: point tid + b T + i M/8 = in[b + i (M/8)/T]).
+template <int M, int T>
+__device__ __forceinline__ void cfft_from_regs(float2* a, const float2* tw, int tid, const float2* in) {
+    using Rx = Radices<M>;
+    static_assert(Rx::r[0] == 8, "the first pass is radix 8");
+    constexpr int NB = (M / 8) / T;
+    float2 v0[NB * 8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v0[b * 8 + i] = in[b + i * NB];
+    fft_pass<8, M, T, true>(a, tw, 1, tid, v0);
+    int Ns = 8;
+#pragma unroll
+    for (int p = 1; p < Rx::n; ++p) {
         if (Rx::r[p] == 8) fft_pass<8, M, T>(a, tw, Ns, tid);
         else fft_pass<4, M, T>(a, tw, Ns, tid);
         Ns *= Rx::r[p];

@@ -57,8 +57,9 @@ struct TileCfg {
     static constexpr int ITERS = 16 / FG;        // iterations that fill a 16-row tile
 };
 
+// (three waves per SIMD up to 1024 points, two for 2048: the register allocation is held to what that needs)
 template <int F, bool MLP>
-__global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
+__global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F == 2048 ? 2 : 3))) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
                                                             float* __restrict__ power, MelFuse mf, int64_t planar,
                                                             MlpFuse ml) {
@@ -154,17 +155,19 @@ __global__ __launch_bounds__(Cfg<F>::WG) void k_stft_power(const float* __restri
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
         const bool valid = f < total_frames;
-        frame_sync<T>();  // previous iteration's reads of this frame's buffer are done
+        // the windowed points go straight from the lane's registers into its first butterfly: lane tid holds exactly
+        // the points tid + q T the first radix-8 pass of this lane reads (no round trip through the frame buffer)
+        float2 wx[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = tid + q * T;
-            A[fft_pad<M>(n)] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
+            wx[q] = make_float2(nx[q].x * half_window<F>(win, 2 * n), nx[q].y * half_window<F>(win, 2 * n + 1));
         }
         // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
         // frames on one wave), where keeping them live across the passes costs more registers than the kernel
         // has: those are fetched after the passes, in flight during the epilogue
         if constexpr (NP <= 8) fetch(grp + gridDim.x);
-        cfft<M, T>(A, twM, tid);
+        cfft_from_regs<M, T>(A, twM, tid, wx);
         if constexpr (NP > 8) fetch(grp + gridDim.x);
         // power spectrum, two bins (p, M - p) per pair of the packed transform: pairs p = tid, tid + T, ... <= M/2
         constexpr int NQ = (M / 2) / T + 1;
