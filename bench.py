@@ -21,9 +21,12 @@ Workloads (BASELINE.json configs):
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
       (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
       the timed region) is the same 512 clips on one GPU -- the base the strong-scaling ratio refers to.
-`--inflight D` keeps D steps in flight per GPU (default 3 for c2; 3 / 4 / 8 for C4 shards of > 128 / <= 128 / <= 64 clips), each on its own pipeline instance with its own
-DISTINCT clips, streams and host thread: while one batch sits in the latency-bound verification rounds
-of its detector the other keeps the chip busy.  The K timed steps are bracketed by barriers as the
+`--inflight D` keeps D steps in flight per GPU (default 6 for c2; 4 / 8 / 12 for C4 shards of > 128 / <= 128 /
+<= 64 clips), each on its own pipeline instance with its own DISTINCT clips, streams and host thread: while one
+batch sits in the latency-bound verification rounds of its detector the others keep the chip busy.  With steps
+overlapping the detector runs in its throughput settings (`config.detector_tuning`: one lane per chunk for both
+followers / both tracker words, IIR candidates in stages; small C4 shards also the layout hint
+`concurrent_calls`) -- every setting gives the same bytes (tests/test_gpu_pipeline.py).  The K timed steps are bracketed by barriers as the
 contract asks (the pipeline's ramp-up and drain are inside the window); `config.latency_ms_per_step` is what
 one step takes meanwhile.
 
@@ -275,16 +278,16 @@ def main():
     # so it is sized for the largest shard
     n_local_max = n_local if workload == "c2" else -(-C4["clips"] // world)
     cap_block = n_local_max * (1024 if workload == "c2" else 256)
-    # steps in flight (measured on one GPU, tools/share_sweep*.sh, ms per step): a rank's 64 clips of C4 at 8
-    # GPUs 9.0 / 7.3 / 6.1 / 5.7 at 1 / 2 / 4 / 8 in flight and 4.6 at 12 with the layout hint below; 128 clips
-    # 9.8 at 4, 8.6 at 8 with the hint; 256 clips 17.8 at 3, 16.7 at 4; all 512: 32.1 / 30.7 / 29.2 at 3 / 4 / 6.
-    # C2 x 16: 12.9 / 12.2 / 11.7 at 3 / 4 / 6.
+    # steps in flight (measured on one GPU, tools/share_sweep*.sh, ms per step, this build): C2 x 16: 11.5 / 10.6 / 10.6 at
+    # 4 / 6 / 8 in flight (C2 x 32: 21.8 / 20.4 at 3 / 4); C4, all 512 clips: 27.1 at 4 or 6; a rank's share alone:
+    # 256 clips 15.3 at 4; 128 clips 8.2 at 8; 64 clips 4.5 at 12 (9.0 / 7.3 / 6.1 / 5.7 at 1 / 2 / 4 / 8 before the
+    # layout hint below).
     if args.inflight > 0:
         D = args.inflight
     elif workload == "c4":
         D = 12 if n_local <= 64 else (8 if n_local <= 128 else 4)
     else:
-        D = 4
+        D = 6
     auto_tuning = {}
     if D >= 2:
         # steps overlap: the detector's throughput setting (fast/slow follower and min/max as one lane per chunk:

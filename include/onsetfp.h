@@ -133,6 +133,8 @@ typedef struct ofp_detect_tuning {
                                     min / max) in one lane instead of two: half the reads of those passes, a longer
                                     dependent chain per lane: more frames/s when calls overlap, a slower lone call.
                                     0 auto (on when concurrent_calls >= 2), 1 always, < 0 never */
+    int64_t fuse_db_sums;        /* the dB pass also forms the per-chunk sums of the slow follower's closed-form guess
+                                    (one pass over the filtered stream instead of two): 0 on, < 0 off */
     int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
                                     at once (0 / 1: this call has the GPU to itself).  The layout of the
                                     speculative passes is chosen for the GPU's share: with k calls in flight each

@@ -1488,6 +1488,45 @@ __global__ __launch_bounds__(256) void k_rect_db(Geom g, const float* __restrict
     }
 }
 
+// k_rect_db and k_ar_sym_local in one pass over the filtered stream (symmetric slow follower, U and the follower
+// chunk multiples of 4): one wave per (chain, follower chunk) turns its chunk into rectified dB in place and,
+// from the same registers, forms the chunk's weighted sum P = sum_t c q^t dB[len-1-t] for the closed-form guess
+// (k_ar_sym_combine) -- the dB stream is not read a second time for it.  The chunk is walked from its end, so
+// the weights only decrease (no overflow for any q in (0, 1)).  P is a guess generator: its summation order does
+// not matter, the chunk passes verify every state bit for bit.
+__global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict__ buf, int64_t n_waves,
+                                                    double* __restrict__ P) {
+    const int64_t id = blockIdx.x;  // one wave per (chain, chunk)
+    if (id >= n_waves) return;
+    const int lane = threadIdx.x;
+    const int64_t j = id % a.n_chunks;
+    const int64_t chain = id / a.n_chunks;
+    const int64_t base = j * a.L;
+    const int64_t len = min(a.L, a.g.U - base);  // a multiple of 4 (the host checks)
+    float4* xs = reinterpret_cast<float4*>(buf + chain * a.g.U + base);
+    const int64_t ng = len >> 2;  // float4 groups; group ng-1-g holds t = 4 g .. 4 g + 3 (from the end)
+    const double c = (double)a.sa, q = 1.0 - c;
+    const double q2 = q * q, q4 = q2 * q2;
+    double q256 = q4;  // q^256 = (q^4)^64
+    for (int i = 0; i < 6; ++i) q256 *= q256;
+    double w = c;      // c q^(4 lane): the weight of this lane's LAST element in its first group
+    for (int i = 0; i < lane; ++i) w *= q4;
+    double acc = 0.0;
+    for (int64_t g = lane; g < ng; g += 64) {
+        float4 v = xs[ng - 1 - g];
+        v.x = ofp_rect_db(v.x, a.floor_db);
+        v.y = ofp_rect_db(v.y, a.floor_db);
+        v.z = ofp_rect_db(v.z, a.floor_db);
+        v.w = ofp_rect_db(v.w, a.floor_db);
+        xs[ng - 1 - g] = v;
+        // t = 4 g + 0 for .w, + 1 for .z, + 2 for .y, + 3 for .x
+        acc += w * ((double)v.w + q * ((double)v.z + q * ((double)v.y + q * (double)v.x)));
+        w *= q256;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) P[id] = acc;
+}
+
 // back to linear (detection.py:753-754), planar in place; the MAIN part is also written to
 // the caller's interleaved [N'][C] array through an LDS tile transpose.
 __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
@@ -2565,35 +2604,46 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     }
     if (phase == 1 || phase == 6) return OFP_OK;  // (no high-pass: the head is the transpose alone)
     OFP_HIP(hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, xt, xdb, chains, p.hp_enabled ? 0 : 1,
-                       p.floor_db);
-    OFP_LAUNCH_CHECK("k_rect_db");
+    ArArgs a;
+    a.g = g;
+    a.xdb = xdb;
+    a.dif = dif;
+    a.fa = p.fast_attack;
+    a.fr = p.fast_release;
+    a.sa = p.slow_attack;
+    a.sr = p.slow_release;
+    a.floor_db = p.floor_db;
+    a.L = l.ar_L;
+    a.W = l.ar_W;
+    a.Wc = l.ar_Wc;
+    a.Wf = l.ar_Wf;
+    a.n_chunks = l.ar_chunks;
+    a.S = l.ar_S;
+    // dB and the per-chunk sums of the closed-form guess in one pass whenever both are wanted and the geometry
+    // allows 16-byte groups (otherwise k_rect_db, then k_ar_sym_local reading the dB stream once more)
+    const bool db_sym = l.ar_sym && p.hp_enabled && (g.U & 3) == 0 && (l.ar_L & 3) == 0 && d->t.fuse_db_sums >= 0;
+    if (db_sym) {
+        hipLaunchKernelGGL(k_rect_db_sym, dim3((unsigned)(chains * l.ar_chunks)), dim3(64), 0, stream, a, xdb,
+                           chains * l.ar_chunks, reinterpret_cast<double*>(ws + l.o_ar_P));
+        OFP_LAUNCH_CHECK("k_rect_db_sym");
+    } else {
+        hipLaunchKernelGGL(k_rect_db, dim3(ew_grid), dim3(256), 0, stream, g, xt, xdb, chains, p.hp_enabled ? 0 : 1,
+                           p.floor_db);
+        OFP_LAUNCH_CHECK("k_rect_db");
+    }
     OFP_HIP(hipEventRecord(ev[2], stream));
 
     // --- followers
     {
-        ArArgs a;
-        a.g = g;
-        a.xdb = xdb;
-        a.dif = dif;
-        a.fa = p.fast_attack;
-        a.fr = p.fast_release;
-        a.sa = p.slow_attack;
-        a.sr = p.slow_release;
-        a.floor_db = p.floor_db;
-        a.L = l.ar_L;
-        a.W = l.ar_W;
-        a.Wc = l.ar_Wc;
-        a.Wf = l.ar_Wf;
-        a.n_chunks = l.ar_chunks;
-        a.S = l.ar_S;
         const int64_t nt = chains * l.ar_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
         if (l.ar_sym) {
             double* P = reinterpret_cast<double*>(ws + l.o_ar_P);
-            hipLaunchKernelGGL(k_ar_sym_local, dim3((unsigned)nt), dim3(64), 0, stream, a, nt, P);
-            OFP_LAUNCH_CHECK("k_ar_sym_local");
+            if (!db_sym) {
+                hipLaunchKernelGGL(k_ar_sym_local, dim3((unsigned)nt), dim3(64), 0, stream, a, nt, P);
+                OFP_LAUNCH_CHECK("k_ar_sym_local");
+            }
             hipLaunchKernelGGL(k_ar_sym_combine, dim3((unsigned)chains), dim3(64), 0, stream, a, (const double*)P,
                                used);
             OFP_LAUNCH_CHECK("k_ar_sym_combine");

@@ -82,6 +82,7 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(hp_early=1, hp_candidates=2, hp_warm=6000, hp_chunk=4096),   # many breaks
                    dict(hp_early=1, hp_dedupe=1, hp_candidates=3, hp_warm=9000, hp_chunk=32768),
                    dict(hp_early=-1, hp_dedupe=1, hp_chunk=32768),
+                   dict(fuse_db_sums=-1),      # dB and the closed-form guess's sums as two passes
                    dict(lane_merge=1),         # fast/slow follower and min/max as one lane per chunk
                    dict(lane_merge=1, ar_chunk=2048, ar_warm=9000, mm_chunk=2048, mm_warm=6000, ar_span=4, mm_span=4),
                    dict(lane_merge=1, mm_chunk=1024, mm_warm=-1),   # no tracker warm-up: the repair passes do the work
