@@ -58,7 +58,11 @@ struct TileCfg {
 };
 
 // (three waves per SIMD up to 1024 points, two for 2048: the register allocation is held to what that needs)
-template <int F, bool MLP>
+// SLIDE (planar input, hop = F/4, frames of up to 1024 points): a wave works through CONSECUTIVE frames of one series
+// and keeps the frame's raw samples in registers; the next frame shares three quarters of them, and the shift by
+// one hop maps lane tid's pair q + NP/4 onto its pair q -- a rotation inside the lane.  Only the quarter that is new
+// is loaded (two 8-byte loads per lane and frame instead of eight, each sample fetched once instead of four times).
+template <int F, bool MLP, bool SLIDE>
 __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F == 2048 ? 2 : 3))) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
                                                             float* __restrict__ power, MelFuse mf, int64_t planar,
@@ -150,11 +154,43 @@ __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F ==
             }
         }
     };
-    fetch(blockIdx.x);
+    // frame of slot `sub` in iteration `it`.  Plain: the workgroups interleave groups of FPW consecutive frames.
+    // SLIDE: workgroup b owns FPW K consecutive frames, slot `sub` the K consecutive ones from b FPW K + sub K.
+    const int64_t n_it = SLIDE ? cdiv(n_groups, (int64_t)gridDim.x)
+                               : (n_groups > (int64_t)blockIdx.x ? cdiv(n_groups - (int64_t)blockIdx.x, (int64_t)gridDim.x) : 0);
+    auto frame_of = [&](int64_t it) -> int64_t {
+        return SLIDE ? ((int64_t)blockIdx.x * FPW + sub) * n_it + it : ((int64_t)blockIdx.x + it * gridDim.x) * FPW + sub;
+    };
+    constexpr int NS = NP / 4;  // SLIDE: pairs per lane that are new in the next frame
+    float2 nw[NS > 0 ? NS : 1];
+    if constexpr (!SLIDE) fetch(blockIdx.x);
     __syncthreads();  // tables ready
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const int64_t f = grp * FPW + sub;  // flattened (clip, channel, hop)
+    for (int64_t it = 0; it < n_it; ++it) {
+        const int64_t grp = (int64_t)blockIdx.x + it * gridDim.x;  // (plain mapping only)
+        const int64_t f = frame_of(it);  // flattened (clip, channel, hop)
         const bool valid = f < total_frames;
+        const bool last_it = it + 1 == n_it;
+        if constexpr (SLIDE) {
+            const uint32_t cc = valid ? (uint32_t)f / H32 : 0u;
+            const uint32_t h = valid ? (uint32_t)f - cc * H32 : 0u;
+            const float2* src = reinterpret_cast<const float2*>(x + (int64_t)cc * planar + (int64_t)h * hop) + tid;
+            if (!valid) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) nx[q] = make_float2(0.0f, 0.0f);
+            } else if (it == 0 || h == 0) {  // the first frame of this wave's run, or of a series: all of it
+#pragma unroll
+                for (int q = 0; q < NP; ++q) nx[q] = src[q * T];
+            } else {  // frame f - 1 of the same series was the previous iteration: rotate, append the new quarter
+#pragma unroll
+                for (int q = 0; q < NP - NS; ++q) nx[q] = nx[q + NS];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) nx[NP - NS + q] = nw[q];
+            }
+            // the new quarter of the next frame: in flight during this frame's FFT
+            const bool more = valid && !last_it && h + 1 < H32 && f + 1 < total_frames;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) nw[q] = more ? src[(hop >> 1) + (NP - NS + q) * T] : make_float2(0.0f, 0.0f);
+        }
         // the windowed points go straight from the lane's registers into its first butterfly: lane tid holds exactly
         // the points tid + q T the first radix-8 pass of this lane reads (no round trip through the frame buffer)
         float2 wx[NP];
@@ -166,9 +202,9 @@ __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F ==
         // the next frame's samples: in flight during this frame's FFT -- unless a lane holds 16+ pairs (2048-point
         // frames on one wave), where keeping them live across the passes costs more registers than the kernel
         // has: those are fetched after the passes, in flight during the epilogue
-        if constexpr (NP <= 8) fetch(grp + gridDim.x);
+        if constexpr (!SLIDE && NP <= 8) fetch(grp + gridDim.x);
         cfft_from_regs<M, T>(A, twM, tid, wx);
-        if constexpr (NP > 8) fetch(grp + gridDim.x);
+        if constexpr (!SLIDE && NP > 8) fetch(grp + gridDim.x);
         // power spectrum, two bins (p, M - p) per pair of the packed transform: pairs p = tid, tid + T, ... <= M/2
         constexpr int NQ = (M / 2) / T + 1;
         float pa[NQ], pb[NQ];
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F ==
         if (MLP) {
             // a tile is pushed through the network when its 16 rows are filled, or at the last iteration
             it_tile += 1;
-            if (it_tile == TC::ITERS || grp + gridDim.x >= n_groups) {
+            if (it_tile == TC::ITERS || last_it) {
                 frame_sync<TC::TG>();  // tile A complete; the group's FFT buffers are idle
                 if ((threadIdx.x % TC::TG) < 64) {
                     const int lane = threadIdx.x & 63;
@@ -361,8 +397,8 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
     }
 }
 
-template <int F, bool MLP>
-int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
+template <int F, bool MLP, bool SLIDE>
+int launch_power_s(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
                    const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
     using G = Cfg<F>;
     using TC = TileCfg<F>;
@@ -380,16 +416,28 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
     if (getenv("OFP_DEBUG_LDS")) fprintf(stderr, "k_stft_power<%d,%d>: %zu bytes of LDS per workgroup\n", F, (int)MLP, lds);
     static size_t attr_set = 0;
     if (lds > 65536 && lds > attr_set) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F, MLP>),
+        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F, MLP, SLIDE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
-    hipLaunchKernelGGL((k_stft_power<F, MLP>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
+    hipLaunchKernelGGL((k_stft_power<F, MLP, SLIDE>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
                        power, mf, planar, ml);
     OFP_LAUNCH_CHECK("k_stft_power");
     return OFP_OK;
+}
+
+template <int F, bool MLP>
+int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
+                   const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
+    // consecutive frames per wave with the shared samples kept in registers: planar input, hop = F/4, 8-byte
+    // aligned pairs (see the kernel)
+    if constexpr (F <= 1024) {
+        if (planar && hop * 4 == F && (planar & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && !getenv("OFP_STFT_NO_SLIDE"))
+            return launch_power_s<F, MLP, true>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
+    }
+    return launch_power_s<F, MLP, false>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
 }
 
 template <int F>

@@ -243,3 +243,33 @@ def test_fused_stft_mel_equals_the_two_kernels():
         xw[:, :, 1000:] = xt
         p4, m4 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar=(xw.data_ptr() + 4000, N + 1000))
         assert torch.equal(p0, p4) and torch.equal(m0, m4)
+
+
+def test_sliding_frames_equal_the_plain_frame_mapping(monkeypatch):
+    """Planar input with hop = n_fft / 4: a wave works through consecutive frames of a series and keeps the shared
+    three quarters of the samples in registers (k_stft_power<.., SLIDE>).  Same arithmetic, so the same bits as the
+    plain mapping (forced through OFP_STFT_NO_SLIDE), for runs that cross series boundaries, a frame count that
+    does not fill the last workgroup, one-frame series and the classifier epilogue."""
+    import torch
+    from onset_fingerprinting_amd import data
+    from onset_fingerprinting_amd.pipeline import seeded_fcnn
+    rng = np.random.default_rng(78)
+    mlp = seeded_fcnn(40, 8).device_mlp(0)
+    for n_fft, C, n_clips, N in ((1024, 5, 3, 30000), (1024, 8, 16, 48000), (1024, 2, 1, 1024), (1024, 3, 7, 1280),
+                                 (512, 4, 2, 20000), (256, 3, 2, 9000)):
+        hop = n_fft // 4
+        x = torch.from_numpy(rng.standard_normal((n_clips, N, C)).astype(np.float32)).cuda()
+        xt = x.transpose(1, 2).contiguous()
+        mb = data.MelBank(48000, n_fft, 40)
+        outs = []
+        for no_slide in (False, True):
+            if no_slide:
+                monkeypatch.setenv("OFP_STFT_NO_SLIDE", "1")
+            else:
+                monkeypatch.delenv("OFP_STFT_NO_SLIDE", raising=False)
+            p, m = data.stft_power_mel_dense(x, n_fft, hop, mb, planar=(xt.data_ptr(), N))
+            p2, m2, l2 = data.stft_power_mel_mlp_dense(x, n_fft, hop, mb, mlp, want_power=True, planar=(xt.data_ptr(), N))
+            outs.append((p.clone(), m.clone(), p2.clone(), m2.clone(), l2.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (n_fft, C, n_clips, N)
+        assert torch.equal(outs[0][0], data.stft_power_dense(x, n_fft, hop))  # and as the interleaved input gives
