@@ -425,6 +425,18 @@ def main():
 
     # ---- untimed extras on the same process: what one clip per step costs (c2) / the whole batch on one GPU (c4)
     extras = {}
+    alone_ms = {}
+    if D > 1 and not rehearsal:
+        # the SAME batch step with nothing else on the GPU (two repetitions after the timed region): what each launch
+        # takes when it does not share the chip with the other steps in flight -- next to the in-flight durations
+        barrier()
+        for _ in range(2):
+            o_a, _b, _l = run_step(0, True)
+            st = dict(o_a["info"]["stage_ms"])
+            st.pop("total")
+            st.update(o_a["spectral_ms"])
+            alone_ms = {k: float(v) for k, v in st.items()}
+        barrier()
     if not args.no_extras:
         if workload == "c2" and (n_local > 1 or D > 1):
             p1 = FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip)
@@ -524,13 +536,21 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": 1, "avg_launch_ms": dom_ms, "algorithmic_bytes_per_frame": dom_bytes,
-                         "note": "per launch: algorithmic bytes of the launch / its duration (HIP events on its stream)"},
+                         "note": "per launch: algorithmic bytes of the launch / its duration (HIP events on its stream) "
+                                 "while the other steps in flight share the GPU with it"},
             "roofline_e2e": {"bound": "hbm", "achieved": e2e_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                              "frac": e2e_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_frame": BYTES_E2E,
                              "note": "whole step: 4 292 B per frame (samples in, rel + |X|^2 + mel + logits out) x frames / ms_per_step"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "detector_passes": {k: passes[k] for k in ("hp_passes", "ar_passes", "mm_passes", "repaired")},
         }
+        if alone_ms.get(dom if dom != "hp" else "hp_candidates"):
+            a_ms = alone_ms[dom if dom != "hp" else "hp_candidates"]
+            a_gbs = dom_bytes * frames_local / (a_ms / 1e3) / 1e9
+            result["roofline"]["alone"] = {"avg_launch_ms": a_ms, "achieved": a_gbs, "unit": "GB/s", "frac": a_gbs / HBM_PEAK_GBS,
+                                           "note": "the same launch of the same batch with nothing else on the GPU "
+                                                   "(one step after the timed region)"}
+            result["stage_ms_alone"] = {k: round(v, 4) for k, v in alone_ms.items()}
         if cand_ms > 0 and passes.get("hp_candidate_steps"):
             flop = 17.0 * passes["hp_candidate_steps"]
             tf = flop / (cand_ms / 1e3) / 1e12

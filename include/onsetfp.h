@@ -135,6 +135,8 @@ typedef struct ofp_detect_tuning {
                                     0 auto (on when concurrent_calls >= 2), 1 always, < 0 never */
     int64_t fuse_db_sums;        /* the dB pass also forms the per-chunk sums of the slow follower's closed-form guess
                                     (one pass over the filtered stream instead of two): 0 on, < 0 off */
+    int64_t sm_segments;         /* hysteresis / cooldown machine time-parallel over the list of visited blocks (clips of
+                                    up to 64 channels): 0 auto (clips of 16384 blocks and more), 1 always, < 0 never */
     int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
                                     at once (0 / 1: this call has the GPU to itself).  The layout of the
                                     speculative passes is chosen for the GPU's share: with k calls in flight each
@@ -173,7 +175,8 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  * 10: total nanoseconds, 11: nanoseconds of the IIR candidate launch(es) (k_hp_candidates, the
  * longest single launch; or the stages k_hp_seg0 .. k_hp_seg_chunk), 12: IIR steps they execute
  * over all their lanes (17 fp32 operations each), 13: staged candidates only: distinct runs that
- * walked a chunk, of chains * chunks * candidates}. */
+ * walked a chunk, of chains * chunks * candidates, 14: 1 if the segmented state machine did not converge within its
+ * pre-enqueued passes and the sequential one decided}. */
 #define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,

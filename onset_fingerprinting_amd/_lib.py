@@ -61,6 +61,7 @@ class DetectTuning(ctypes.Structure):
         ("hp_early", ctypes.c_int64),
         ("lane_merge", ctypes.c_int64),
         ("fuse_db_sums", ctypes.c_int64),
+        ("sm_segments", ctypes.c_int64),
         ("concurrent_calls", ctypes.c_int64),
     ]
 

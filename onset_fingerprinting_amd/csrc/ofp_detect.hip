@@ -1712,43 +1712,69 @@ struct VisArgs {
     int32_t* nv;                  // [clips]
 };
 
-__global__ __launch_bounds__(256) void k_visits(VisArgs a) {
+// Three launches, all parallel over tiles of 256 blocks: count the visited blocks of every tile, scan the
+// counts of a clip (one wave), then every tile copies its records behind those of the tiles before it.  (One
+// workgroup per clip walking its tiles in order took 2.5 ms on C3's 56 250 blocks.)
+__global__ __launch_bounds__(256) void k_visit_count(VisArgs a, int32_t* __restrict__ tile_cnt, int64_t n_tiles) {
+    __shared__ int s_w[4];
+    const int64_t clip = blockIdx.y, tile = blockIdx.x;
+    const int64_t j = tile * 256 + threadIdx.x;
+    const bool f = j < a.nb && a.vflag[clip * a.nb + j] != 0u;
+    const unsigned long long m0 = __ballot(f);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(m0);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[clip * n_tiles + tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(64) void k_visit_scan(int32_t* __restrict__ tile_cnt, int64_t n_tiles, int32_t* __restrict__ nv) {
     OFP_LATENCY_BOUND_KERNEL();
+    const int64_t clip = blockIdx.x;
+    const int lane = threadIdx.x;
+    int32_t* t = tile_cnt + clip * n_tiles;
+    int base = 0;
+    for (int64_t i0 = 0; i0 < n_tiles; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const int v = i < n_tiles ? t[i] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (i < n_tiles) t[i] = base + inc - v;  // exclusive offset of tile i
+        base += __shfl(inc, 63);
+    }
+    if (lane == 0) nv[clip] = base;
+}
+
+__global__ __launch_bounds__(256) void k_visit_scatter(VisArgs a, const int32_t* __restrict__ tile_off, int64_t n_tiles) {
     __shared__ int s_w[4];
     __shared__ uint8_t s_idx[4][64];  // per wave: lane of its q-th visited block
-    const int64_t clip = blockIdx.x;
+    const int64_t clip = blockIdx.y, tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
-    int base = 0;
-    for (int64_t j0 = 0; j0 < a.nb; j0 += 256) {
-        const int64_t j = j0 + threadIdx.x;
-        const bool f = j < a.nb && a.vflag[clip * a.nb + j] != 0u;
-        const unsigned long long m0 = __ballot(f);
-        if (lane == 0) s_w[wave] = __popcll(m0);
-        if (f) s_idx[wave][__popcll(m0 & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) woff += s_w[w];
-            tot += s_w[w];
-        }
-        // the wave copies the records of its visited blocks, lanes over (visited block, channel):
-        // all loads of a step are independent
-        const int n_el = __popcll(m0) * C;
-        for (int e = lane; e < n_el; e += 64) {
-            const int q = e / C, c = e - q * C;
-            const int64_t jj = j0 + wave * 64 + s_idx[wave][q];
-            const int64_t pos = clip * a.nb + base + woff + q;
-            if (c == 0) a.vis_j[pos] = (int32_t)jj;
-            const int64_t src = (clip * a.nb + jj) * C + c;
-            a.vfc[pos * C + c] = a.fc[src];
-            a.vlb[pos * C + c] = a.lb[src];
-            a.vpc[pos * C + c] = jj > 0 ? a.pc[src - C] : -1;
-        }
-        base += tot;
-        __syncthreads();
+    const int64_t j0 = tile * 256;
+    const int64_t j = j0 + threadIdx.x;
+    const bool f = j < a.nb && a.vflag[clip * a.nb + j] != 0u;
+    const unsigned long long m0 = __ballot(f);
+    if (lane == 0) s_w[wave] = __popcll(m0);
+    if (f) s_idx[wave][__popcll(m0 & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_w[w];
+    const int base = tile_off[clip * n_tiles + tile];
+    // the wave copies the records of its visited blocks, lanes over (visited block, channel):
+    // all loads of a step are independent
+    const int n_el = __popcll(m0) * C;
+    for (int e = lane; e < n_el; e += 64) {
+        const int q = e / C, c = e - q * C;
+        const int64_t jj = j0 + wave * 64 + s_idx[wave][q];
+        const int64_t pos = clip * a.nb + base + woff + q;
+        if (c == 0) a.vis_j[pos] = (int32_t)jj;
+        const int64_t src = (clip * a.nb + jj) * C + c;
+        a.vfc[pos * C + c] = a.fc[src];
+        a.vlb[pos * C + c] = a.lb[src];
+        a.vpc[pos * C + c] = jj > 0 ? a.pc[src - C] : -1;
     }
-    if (threadIdx.x == 0) a.nv[clip] = base;
 }
 
 // ---- hysteresis / cooldown state machine over the blocks of one clip
@@ -1951,6 +1977,189 @@ __global__ __launch_bounds__(64) void k_state_machine(SmArgs a) {
     if (lane == 0) a.counts[clip] = count;
 }
 
+// ---- the same machine, time-parallel over the visit list (long clips of up to 64 channels: C3 is ONE clip of
+// 56 250 blocks, whose visits one wave walked in 5 ms).  The visits of a clip are cut into segments of SM_SEG;
+// pass 0 gives every segment a start state from a warm-up over the SM_WARM visits before it (from the idle
+// state -- the cooldown runs out within a few blocks and a latched channel is released at the first block with a
+// row below its off threshold, so the machine forgets quickly), runs the segment and records its end state and
+// number of onsets; the verification passes re-run exactly those segments whose start state differs from the
+// end state of the segment before (chunk-Jacobi, as for the followers); offsets = prefix sums of the counts; a
+// last pass writes the records.  The host enqueues everything without a synchronisation and reads the last
+// pass's change counter with the call's final one: not converged (never seen) = the sequential kernel runs.
+constexpr int SM_SEG = 256, SM_WARM = 64;
+
+struct SmSegArgs {
+    int32_t* used;    // [clips][n_seg][64][2] start state of every segment: {latched, cooldown counter}
+    int32_t* endA;    // [clips][n_seg][64][2] end states, two buffers (pass parity)
+    int32_t* endB;
+    int32_t* cnt;     // [clips][n_seg] onsets of the segment, then (k_sm_offsets) its first record
+    int64_t n_seg;
+};
+
+// visits [kb, ke) of `clip` for up to 64 channels (lane = channel), state in registers; WRITE: records at `count`
+template <bool WRITE>
+__device__ __forceinline__ void sm_walk64(const SmArgs& a, int64_t clip, int64_t kb, int64_t ke, int& jp, int64_t& r_deb,
+                                          int& r_state, int64_t& count, int32_t* t_fc, int32_t* t_lb, int32_t* t_pc,
+                                          int32_t* t_j, int TB) {
+    const int C = a.g.C, B = a.g.B, lane = threadIdx.x;
+    const int32_t* fc_g = a.vfc + clip * a.nb * C;
+    const int32_t* lb_g = a.vlb + clip * a.nb * C;
+    const int32_t* pc_g = a.vpc + clip * a.nb * C;
+    const int32_t* vj_g = a.vis_j + clip * a.nb;
+    ofp_onset* rec = a.records + clip * a.cap;
+    const bool act = lane < C;
+    for (int64_t k0 = kb; k0 < ke; k0 += TB) {
+        const int nblk = (int)min<int64_t>(TB, ke - k0);
+        __syncthreads();
+        for (int e = lane; e < nblk * C; e += 64) {
+            t_fc[e] = fc_g[k0 * C + e];
+            t_lb[e] = lb_g[k0 * C + e];
+            t_pc[e] = pc_g[k0 * C + e];
+        }
+        if (lane < nblk) t_j[lane] = vj_g[k0 + lane];
+        __syncthreads();
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int j = t_j[bi];
+            const int skipped = j - jp - 1;
+            int f = -1, lbv = -1, pcv = -1;
+            if (act) {
+                f = t_fc[bi * C + lane];
+                lbv = t_lb[bi * C + lane];
+                pcv = t_pc[bi * C + lane];
+            }
+            bool on = false;
+            int oi = 0;
+            if (act) {
+                if (skipped > 0 && r_deb > 0) r_deb -= (int64_t)B * min<int64_t>(skipped, (r_deb + B - 1) / B);
+                if (r_state && pcv > jp) r_state = 0;
+                const bool gate = !r_state && r_deb < 1;  // :764-768 (block-start values)
+                on = gate && f >= 0;
+                oi = on ? f : 0;                          // :774
+            }
+            int mx = 0;                                   // :790 on_indices.max() over ALL channels
+            {
+                unsigned long long fm = __ballot(oi > 0);
+                while (fm) {
+                    const int l = __builtin_ctzll(fm);
+                    mx = max(mx, __builtin_amdgcn_readlane(oi, l));
+                    fm &= fm - 1;
+                }
+            }
+            if (act) {
+                if (on) {                                 // :778-779
+                    r_state = 1;
+                    r_deb = a.cooldown;
+                }
+                if (r_deb > 0) r_deb -= B;                // :780
+                if (lbv >= mx) r_state = 0;               // :784-791
+            }
+            const unsigned long long m = __ballot(on);
+            if (WRITE && on) {
+                const int64_t pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < a.cap) {
+                    rec[pos].clip = (int32_t)clip + a.clip_base;
+                    rec[pos].channel = lane;
+                    rec[pos].sample = (int64_t)j * B + oi;  // detection.py:80
+                }
+            }
+            count += __popcll(m);
+            jp = j;
+        }
+    }
+}
+
+// pass 0: warm-up + segment; pass >= 1: verify / repair; pass < 0: write the records (offsets in s.cnt)
+__global__ __launch_bounds__(64) void k_sm_seg(SmArgs a, SmSegArgs s, int pass, int* __restrict__ changed) {
+    OFP_LATENCY_BOUND_KERNEL();
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = a.g.C, lane = threadIdx.x;
+    const int TB = max(1, min(64, 1024 / C));
+    int32_t* t_fc = reinterpret_cast<int32_t*>(smem);
+    int32_t* t_lb = t_fc + TB * C;
+    int32_t* t_pc = t_lb + TB * C;
+    int32_t* t_j = t_pc + TB * C;
+    const int64_t seg = blockIdx.x, clip = blockIdx.y;
+    const int64_t nvis = a.nv[clip];
+    const int64_t k0 = seg * SM_SEG;
+    if (k0 >= nvis) return;  // (empty segments have no state to pass on: nothing reads them)
+    const int64_t k1 = min<int64_t>(k0 + SM_SEG, nvis);
+    const int64_t si = ((clip * s.n_seg + seg) * 64 + lane) * 2;
+    int32_t* end_prev = (pass & 1) ? s.endA : s.endB;   // pass p reads what pass p-1 wrote
+    int32_t* end_next = (pass & 1) ? s.endB : s.endA;
+    const int32_t* vj_g = a.vis_j + clip * a.nb;
+    int r_state = 0;
+    int64_t r_deb = 0, count = 0;
+    int jp;
+    if (pass == 0) {
+        const int64_t kw = max<int64_t>(k0 - SM_WARM, 0);
+        jp = kw > 0 ? vj_g[kw - 1] : -1;
+        sm_walk64<false>(a, clip, kw, k0, jp, r_deb, r_state, count, t_fc, t_lb, t_pc, t_j, TB);
+        s.used[si] = r_state;
+        s.used[si + 1] = (int32_t)max<int64_t>(r_deb, 0);  // (every value <= 0 behaves like 0: one representative)
+        count = 0;
+        sm_walk64<false>(a, clip, k0, k1, jp, r_deb, r_state, count, t_fc, t_lb, t_pc, t_j, TB);
+        s.endA[si] = r_state;           // pass 0 writes A (pass 1 reads A)
+        s.endA[si + 1] = (int32_t)max<int64_t>(r_deb, 0);
+        if (lane == 0) s.cnt[clip * s.n_seg + seg] = (int32_t)count;
+        return;
+    }
+    if (pass > 0) {
+        bool same = true;
+        if (seg > 0) {
+            const int64_t pi = ((clip * s.n_seg + seg - 1) * 64 + lane) * 2;
+            const int32_t p0 = end_prev[pi], p1 = end_prev[pi + 1];
+            same = s.used[si] == p0 && s.used[si + 1] == p1;
+            same = __all(same);
+            if (!same) {
+                s.used[si] = p0;
+                s.used[si + 1] = p1;
+            }
+        }
+        if (same) {
+            end_next[si] = end_prev[si];
+            end_next[si + 1] = end_prev[si + 1];
+            return;
+        }
+        if (lane == 0) atomicAdd(changed, 1);
+        r_state = s.used[si];
+        r_deb = s.used[si + 1];
+        jp = vj_g[k0 - 1];
+        sm_walk64<false>(a, clip, k0, k1, jp, r_deb, r_state, count, t_fc, t_lb, t_pc, t_j, TB);
+        end_next[si] = r_state;
+        end_next[si + 1] = (int32_t)max<int64_t>(r_deb, 0);
+        if (lane == 0) s.cnt[clip * s.n_seg + seg] = (int32_t)count;
+        return;
+    }
+    // write pass
+    r_state = s.used[si];
+    r_deb = s.used[si + 1];
+    jp = k0 > 0 ? vj_g[k0 - 1] : -1;
+    count = s.cnt[clip * s.n_seg + seg];  // first record of this segment (k_sm_offsets)
+    sm_walk64<true>(a, clip, k0, k1, jp, r_deb, r_state, count, t_fc, t_lb, t_pc, t_j, TB);
+}
+
+// per clip: the segments' onset counts -> their first record; the clip's total
+__global__ __launch_bounds__(64) void k_sm_offsets(SmArgs a, SmSegArgs s) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t clip = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t n_used = cdiv((int64_t)a.nv[clip], SM_SEG);
+    int32_t* t = s.cnt + clip * s.n_seg;
+    long long base = 0;
+    for (int64_t i0 = 0; i0 < n_used; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const int v = i < n_used ? t[i] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (i < n_used) t[i] = (int32_t)(base + inc - v);
+        base += __shfl(inc, 63);
+    }
+    if (lane == 0) a.counts[clip] = base;
+}
+
 // ---- backtracking (detection.py:800-825 == envelope_follower.c:59-85 with the Python loop
 // bound), one thread per onset.  The ring buffer of the reference (last N rows after writing
 // the current block) is a window of the main relative envelope; rows before the stream start
@@ -2007,6 +2216,7 @@ struct Layout {
     int64_t nb;
     int64_t hp_L, hp_W, hp_chunks, hp_delta;
     int hp_R, hp_S, hp_span;
+    bool sm_seg;     // hysteresis machine time-parallel over the visit list (k_sm_seg; long clips of <= 64 channels)
     bool merge;      // followers / tracker: the two recurrences of a chunk in one lane (k_*_both; saturated launches)
     bool hp_early;   // whole runs stop early at a sub-chunk boundary (k_hp_run)
     bool hp_staged;  // candidates in stages with duplicate runs removed between them (k_hp_seg*)
@@ -2016,7 +2226,7 @@ struct Layout {
     int tu;  // time steps per transpose tile
     // byte offsets
     int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
-        o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_flags, o_zero, zero_bytes, total;
+        o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_vtile, o_smseg, o_flags, o_zero, zero_bytes, total;
 };
 
 int64_t pick(int64_t user, int64_t dflt) { return user > 0 ? user : dflt; }
@@ -2186,6 +2396,15 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_visj = take(n_clips * l.nb * 4);
     l.o_vrec = take(3 * n_clips * l.nb * g.C * 4);
     l.o_nv = take(n_clips * 4);
+    l.o_vtile = take(n_clips * cdiv(std::max<int64_t>(l.nb, 1), 256) * 4);
+    // segmented state machine: long clips only (a batch of short clips has its parallelism across clips, and the
+    // segments cost a few launches), at most 64 channels, cooldown counters that fit 32 bits
+    l.sm_seg = d->t.sm_segments >= 0 && g.C <= 64 && p.cooldown < (1ll << 30) && g.B < (1 << 30) &&
+               (l.nb >= 16384 || d->t.sm_segments > 0) && l.nb > SM_SEG;
+    {
+        const int64_t n_seg = cdiv(std::max<int64_t>(l.nb, 1), SM_SEG);
+        l.o_smseg = take(l.sm_seg ? n_clips * n_seg * (3 * 64 * 2 * 4 + 4) : 0);
+    }
     // everything that has to start a call as zero lies in one region: one fill per call
     l.o_flags = take(OFP_N_COUNTERS * 4);  // pass / round counters, one fresh slot per use
     l.o_zero = l.o_flags;
@@ -2760,8 +2979,17 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                            l.nb, g.C);
         OFP_LAUNCH_CHECK("k_last_clear");
     }
-    hipLaunchKernelGGL(k_visits, dim3((unsigned)n_clips), dim3(256), 0, stream, va);
-    OFP_LAUNCH_CHECK("k_visits");
+    if (l.nb > 0) {
+        const int64_t n_tiles = cdiv(l.nb, 256);
+        int32_t* vtile = reinterpret_cast<int32_t*>(ws + l.o_vtile);
+        hipLaunchKernelGGL(k_visit_count, dim3((unsigned)n_tiles, (unsigned)n_clips), dim3(256), 0, stream, va, vtile, n_tiles);
+        hipLaunchKernelGGL(k_visit_scan, dim3((unsigned)n_clips), dim3(64), 0, stream, vtile, n_tiles, va.nv);
+        hipLaunchKernelGGL(k_visit_scatter, dim3((unsigned)n_tiles, (unsigned)n_clips), dim3(256), 0, stream, va,
+                           (const int32_t*)vtile, n_tiles);
+        OFP_LAUNCH_CHECK("k_visit_count / k_visit_scan / k_visit_scatter");
+    } else {
+        OFP_HIP(hipMemsetAsync(va.nv, 0, n_clips * sizeof(int32_t), stream));
+    }
     SmArgs sm;
     sm.g = g;
     sm.nb = l.nb;
@@ -2776,7 +3004,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sm.records = d_records;
     sm.counts = d_counts;
     sm.clip_base = 0;
-    {
+    auto sequential_machine = [&]() -> int {
         const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
         size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)3 * tb * g.C * 4 + 64 * 4 + 16;
         if (lds > 65536)
@@ -2784,8 +3012,35 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
         OFP_LAUNCH_CHECK("k_state_machine");
+        return OFP_OK;
+    };
+    int* sm_flag = nullptr;  // change counter of the last verification pass of the segmented machine
+    if (l.sm_seg && l.nb > 0) {
+        SmSegArgs ss;
+        ss.n_seg = cdiv(l.nb, SM_SEG);
+        const int64_t words = n_clips * ss.n_seg * 64 * 2;
+        ss.used = reinterpret_cast<int32_t*>(ws + l.o_smseg);
+        ss.endA = ss.used + words;
+        ss.endB = ss.endA + words;
+        ss.cnt = ss.endB + words;
+        const int tb = std::max(1, std::min(64, 1024 / g.C));
+        const size_t lds = (size_t)3 * tb * g.C * 4 + 64 * 4;
+        const dim3 grid((unsigned)ss.n_seg, (unsigned)n_clips);
+        constexpr int V = 4;  // verification passes enqueued ahead (a pass that finds nothing costs microseconds)
+        int* c = nullptr;
+        if (int rc = ctr.take(V, &c)) return rc;
+        hipLaunchKernelGGL(k_sm_seg, grid, dim3(64), lds, stream, sm, ss, 0, c);
+        for (int q = 1; q <= V; ++q) hipLaunchKernelGGL(k_sm_seg, grid, dim3(64), lds, stream, sm, ss, q, c + q - 1);
+        hipLaunchKernelGGL(k_sm_offsets, dim3((unsigned)n_clips), dim3(64), 0, stream, sm, ss);
+        hipLaunchKernelGGL(k_sm_seg, grid, dim3(64), lds, stream, sm, ss, -1, c);
+        OFP_LAUNCH_CHECK("k_sm_seg / k_sm_offsets");
+        sm_flag = c + V - 1;
+        OFP_HIP(hipMemcpyAsync(d->h_flags + 40, sm_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    } else {
+        if (int rc = sequential_machine()) return rc;
     }
-    if (p.backtrack && cap > 0) {
+    auto backtrack = [&]() -> int {
+        if (!(p.backtrack && cap > 0)) return OFP_OK;
         BtArgs bt;
         bt.g = g;
         bt.rel = rel;
@@ -2798,9 +3053,20 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         bt.tol = p.backtrack_tol;
         hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
         OFP_LAUNCH_CHECK("k_backtrack");
-    }
+        return OFP_OK;
+    };
+    if (int rc = backtrack()) return rc;
     OFP_HIP(hipEventRecord(ev[6], stream));
     OFP_HIP(hipStreamSynchronize(stream));
+    if (sm_flag && d->h_flags[40] != 0) {
+        // the last verification pass still changed a segment's start state (a machine that does not forget within
+        // four segments): the sequential machine decides
+        if (int rc = sequential_machine()) return rc;
+        if (int rc = backtrack()) return rc;
+        OFP_HIP(hipEventRecord(ev[6], stream));
+        OFP_HIP(hipStreamSynchronize(stream));
+        info[14] = 1;
+    }
     // stage durations in nanoseconds (HIP events on the launch stream)
     for (int k = 0; k < 6; ++k) {
         float ms = 0.0f;

@@ -66,6 +66,8 @@ def random_case(rng):
         tuning["mm_warm"] = int(rng.choice([0, 4096, 49152])) or -1
     if rng.random() < 0.4:
         tuning["lane_merge"] = int(rng.choice([-1, 1]))
+    if rng.random() < 0.5:
+        tuning["sm_segments"] = 1   # (clips this short take the sequential machine by default)
     return x, kw, tuning
 
 

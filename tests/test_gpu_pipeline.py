@@ -83,6 +83,8 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(hp_early=1, hp_dedupe=1, hp_candidates=3, hp_warm=9000, hp_chunk=32768),
                    dict(hp_early=-1, hp_dedupe=1, hp_chunk=32768),
                    dict(fuse_db_sums=-1),      # dB and the closed-form guess's sums as two passes
+                   dict(sm_segments=1),        # the hysteresis machine time-parallel over the visit list
+                   dict(sm_segments=-1),
                    dict(lane_merge=1),         # fast/slow follower and min/max as one lane per chunk
                    dict(lane_merge=1, ar_chunk=2048, ar_warm=9000, mm_chunk=2048, mm_warm=6000, ar_span=4, mm_span=4),
                    dict(lane_merge=1, mm_chunk=1024, mm_warm=-1),   # no tracker warm-up: the repair passes do the work
@@ -129,7 +131,9 @@ def test_c3_size_properties_tuning_independence_and_channel_subsets(mods):
     x = synth.c2_drums(100.0, 64, SR, seed=2)
     xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
     ref = None
-    for tuning in (None, dict(hp_chunk=8192, hp_candidates=16, ar_chunk=4096, mm_chunk=4096), None):
+    for tuning in (None, dict(hp_chunk=8192, hp_candidates=16, ar_chunk=4096, mm_chunk=4096), None,
+                   dict(sm_segments=1),  # 64 channels' hysteresis machine in segments (automatic from 16 384 blocks)
+                   dict(sm_segments=1, lane_merge=1, hp_dedupe=1)):
         bd = detection.BatchDetector(64, 512, sr=SR)
         if tuning:
             bd.set_tuning(**tuning)

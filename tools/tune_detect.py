@@ -2,7 +2,7 @@
 
     python tools/tune_detect.py c4|c2x8|c3s '<json list of tuning dicts>'
 
-c4: 512 clips x 4 ch x 10 s; c2x8: 8 clips x 8 ch x 60 s; c3s: 1 clip x 64 ch x 60 s (a tenth of C3).
+c4: 512 clips x 4 ch x 10 s; c2x8: 8 clips x 8 ch x 60 s; c3s: 1 clip x 64 ch x 60 s (a tenth of C3); c3: all of it.
 Every setting gives the same bytes (checked against the first one); prints ms per call and the stages."""
 import json
 import sys
@@ -27,6 +27,9 @@ def main():
     elif kind == "c2x8":
         xs = bench.synth_batch("c2", [1 + 7919 * i for i in range(8)], 60.0, 8, 8)
         B = 256
+    elif kind == "c3":
+        xs = [synth.c3_stream(600.0, 64, 48000, seed=2)]   # BASELINE config C3 at full size
+        B = 512
     else:
         xs = [synth.c3_stream(60.0, 64, 48000, seed=2)]
         B = 512
