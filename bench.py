@@ -489,9 +489,9 @@ def main():
         passes = out["info"]
         stage_bytes = dict(hp=BYTES_DETECT, db=BYTES_DETECT, ar=BYTES_DETECT, rel=BYTES_DETECT, mm=BYTES_DETECT // 2,
                            logic=BYTES_DETECT // 2, stft_mel=4 * HOP + BYTES_SPECTRUM + BYTES_FINGERPRINT, mlp=0)
-        kernels = {"hp": "k_hp_candidates", "ar": "k_ar_sym_local+k_ar_sym_combine+k_ar_warm2+k_ar_chunk",
-                   "mm": "k_mm_warm2+k_mm_chunk", "db": "k_rect_db", "rel": "k_rel_out",
-                   "logic": "k_block_scan+k_last_clear+k_visits+k_state_machine",
+        kernels = {"hp": "k_hp_candidates", "ar": "k_ar_sym_combine+k_ar_warm2|k_ar_warm_both+k_ar_chunk",
+                   "mm": "k_mm_warm2+k_mm_chunk | k_mm_warm_both+k_mm_chunk_both", "db": "k_rect_db_sym (dB + the sums of the follower guess)",
+                   "rel": "k_rel_out", "logic": "k_block_scan+k_last_clear+k_visit_count/scan/scatter+k_state_machine",
                    "stft_mel": "k_stft_power<1024, mlp> (mel + FCNN in the epilogue)", "mlp": "-"}
         # The dominant KERNEL = the single launch with the longest duration among those timed one by one (HIP events on
         # their streams): k_stft_power, k_rect_db, k_rel_out and the IIR candidate launch when it is ONE kernel

@@ -1645,17 +1645,30 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
         // row; zeros before the first main block) with the threshold
         float carry = (j == 0) ? 0.0f : r[-1];
         int first = -1, last = -1;
-        for (int t0 = 0; t0 < B; t0 += 64) {
-            const int t = t0 + lane;
-            const float v = t < B ? r[t] : 0.0f;
-            float prev = __shfl_up(v, 1);
-            if (lane == 0) prev = carry;
-            const bool below_before = (t == 0) ? ((double)prev < on0) : (prev < on);
-            const unsigned long long mc = __ballot(t < B && v > on && below_before);
-            const unsigned long long mb = __ballot(t < B && v < off);
-            if (first < 0 && mc) first = t0 + __builtin_ctzll(mc);
-            if (mb) last = t0 + 63 - __builtin_clzll(mb);
-            carry = __shfl(v, 63);
+        // the rows of the block, 64 per step; the loads of up to 8 steps are issued together (one memory round
+        // trip per 512 rows instead of one per 64)
+        for (int tb = 0; tb < B; tb += 512) {
+            float vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t = tb + 64 * q + lane;
+                vv[q] = t < B ? r[t] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t0 = tb + 64 * q;
+                if (t0 >= B) break;
+                const int t = t0 + lane;
+                const float v = vv[q];
+                float prev = __shfl_up(v, 1);
+                if (lane == 0) prev = carry;
+                const bool below_before = (t == 0) ? ((double)prev < on0) : (prev < on);
+                const unsigned long long mc = __ballot(t < B && v > on && below_before);
+                const unsigned long long mb = __ballot(t < B && v < off);
+                if (first < 0 && mc) first = t0 + __builtin_ctzll(mc);
+                if (mb) last = t0 + 63 - __builtin_clzll(mb);
+                carry = __shfl(v, 63);
+            }
         }
         if (lane == 0) {
             a.first_cross[oi] = first;
