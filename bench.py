@@ -21,8 +21,7 @@ Workloads (BASELINE.json configs):
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
       (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
       the timed region) is the same 512 clips on one GPU -- the base the strong-scaling ratio refers to.
-`--inflight D` keeps D steps in flight per GPU (default 6 for c2; 4 / 8 / 12 for C4 shards of > 128 / <= 128 /
-<= 64 clips), each on its own pipeline instance with its own DISTINCT clips, streams and host thread: while one
+`--inflight D` keeps D steps in flight per GPU (default 6 for c2; 6 / 12 for C4 shards of > 128 / <= 128 clips), each on its own pipeline instance with its own DISTINCT clips, streams and host thread: while one
 batch sits in the latency-bound verification rounds of its detector the others keep the chip busy.  With steps
 overlapping the detector runs in its throughput settings (`config.detector_tuning`: one lane per chunk for both
 followers / both tracker words, IIR candidates in stages; small C4 shards also the layout hint
@@ -279,13 +278,13 @@ def main():
     n_local_max = n_local if workload == "c2" else -(-C4["clips"] // world)
     cap_block = n_local_max * (1024 if workload == "c2" else 256)
     # steps in flight (measured on one GPU, tools/share_sweep*.sh, ms per step, this build): C2 x 16: 11.5 / 10.6 / 10.6 at
-    # 4 / 6 / 8 in flight (C2 x 32: 21.8 / 20.4 at 3 / 4); C4, all 512 clips: 27.1 at 4 or 6; a rank's share alone:
-    # 256 clips 15.3 at 4; 128 clips 8.2 at 8; 64 clips 4.5 at 12 (9.0 / 7.3 / 6.1 / 5.7 at 1 / 2 / 4 / 8 before the
-    # layout hint below).
+    # 4 / 6 / 8 in flight (C2 x 32: 21.8 / 20.4 at 3 / 4); C4, all 512 clips: 24.9 / 23.8 at 4 / 6; a rank's share
+    # alone: 256 clips 14.4 / 13.7 at 4 / 6; 128 clips 7.4 / 7.0 at 8 / 12; 64 clips 4.1 at 12, 4.7 at 16 (9.0 / 7.3 / 6.1 /
+    # 5.7 at 1 / 2 / 4 / 8 before the layout hint below).
     if args.inflight > 0:
         D = args.inflight
     elif workload == "c4":
-        D = 12 if n_local <= 64 else (8 if n_local <= 128 else 4)
+        D = 12 if n_local <= 128 else 6
     else:
         D = 6
     auto_tuning = {}
@@ -548,8 +547,8 @@ def main():
             a_ms = alone_ms[dom if dom != "hp" else "hp_candidates"]
             a_gbs = dom_bytes * frames_local / (a_ms / 1e3) / 1e9
             result["roofline"]["alone"] = {"avg_launch_ms": a_ms, "achieved": a_gbs, "unit": "GB/s", "frac": a_gbs / HBM_PEAK_GBS,
-                                           "note": "the same launch of the same batch with nothing else on the GPU "
-                                                   "(one step after the timed region)"}
+                                           "note": "the same launch in the same batch step with no OTHER step on the GPU (one step "
+                                                   "after the timed region; the launch still runs beside its own step's detector head)"}
             result["stage_ms_alone"] = {k: round(v, 4) for k, v in alone_ms.items()}
         if cand_ms > 0 and passes.get("hp_candidate_steps"):
             flop = 17.0 * passes["hp_candidate_steps"]
