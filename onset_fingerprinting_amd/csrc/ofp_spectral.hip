@@ -433,7 +433,7 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
                    const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
     // consecutive frames per wave with the shared samples kept in registers: planar input, hop = F/4, 8-byte
     // aligned pairs (see the kernel)
-    if constexpr (F <= 1024) {
+    if constexpr (F <= 2048) {
         if (planar && hop * 4 == F && (planar & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && !getenv("OFP_STFT_NO_SLIDE"))
             return launch_power_s<F, MLP, true>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
     }

@@ -256,7 +256,7 @@ def test_sliding_frames_equal_the_plain_frame_mapping(monkeypatch):
     rng = np.random.default_rng(78)
     mlp = seeded_fcnn(40, 8).device_mlp(0)
     for n_fft, C, n_clips, N in ((1024, 5, 3, 30000), (1024, 8, 16, 48000), (1024, 2, 1, 1024), (1024, 3, 7, 1280),
-                                 (512, 4, 2, 20000), (256, 3, 2, 9000)):
+                                 (512, 4, 2, 20000), (256, 3, 2, 9000), (2048, 3, 2, 40000), (2048, 64, 1, 6144)):
         hop = n_fft // 4
         x = torch.from_numpy(rng.standard_normal((n_clips, N, C)).astype(np.float32)).cuda()
         xt = x.transpose(1, 2).contiguous()
