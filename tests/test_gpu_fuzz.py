@@ -67,7 +67,7 @@ def random_case(rng):
     if rng.random() < 0.4:
         tuning["lane_merge"] = int(rng.choice([-1, 1]))
     if rng.random() < 0.5:
-        tuning["sm_segments"] = 1   # (clips this short take the sequential machine by default)
+        tuning["sm_segments"] = int(rng.choice([1, 1, 2]))   # (clips this short take the sequential machine by default)
     return x, kw, tuning
 
 

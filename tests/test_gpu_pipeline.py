@@ -84,6 +84,7 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(hp_early=-1, hp_dedupe=1, hp_chunk=32768),
                    dict(fuse_db_sums=-1),      # dB and the closed-form guess's sums as two passes
                    dict(sm_segments=1),        # the hysteresis machine time-parallel over the visit list
+                   dict(sm_segments=2),        # ... and the sequential machine deciding after it (the fallback path)
                    dict(sm_segments=-1),
                    dict(lane_merge=1),         # fast/slow follower and min/max as one lane per chunk
                    dict(lane_merge=1, ar_chunk=2048, ar_warm=9000, mm_chunk=2048, mm_warm=6000, ar_span=4, mm_span=4),
