@@ -322,3 +322,18 @@ def test_hundreds_of_iir_verification_rounds_stay_exact(det):
     x = synth.drum_hits(2, 6.5, SR, seed=77, period=0.31)
     info, n = check_clip(det, x, tuning=dict(hp_chunk=1024, hp_warm=-1, hp_candidates=1), block_size=128, sr=SR)
     assert info["hp_passes"] > 260 and n > 20
+
+
+THROUGHPUT = dict(lane_merge=1, hp_dedupe=1, hp_early=1, sm_segments=1)
+
+
+@pytest.mark.parametrize("B,sr,C,N", [(100, 44100, 3, 133333), (250, 48000, 2, 100001), (441, 44100, 5, 88200),
+                                      (30, 22050, 1, 50003), (512, 96000, 7, 200000)])
+@pytest.mark.parametrize("tuning", [None, THROUGHPUT])
+def test_sizes_that_are_multiples_of_nothing(det, B, sr, C, N, tuning):
+    """Block sizes, rates and lengths that break every alignment the fast paths rely on (16-byte groups, block-aligned
+    warm-up, whole blocks): the 16-byte stores of the IIR writers, the fused dB / follower-sum pass and the staged
+    candidates must fall back or cope; in both layouts the result is the oracle's."""
+    x = synth.drum_hits(C, N / sr + 0.01, sr, seed=B + C, period=0.19)[:N]
+    check_clip(det, x, tuning=tuning, block_size=B, sr=sr)
+    check_clip(det, x, tuning=tuning, block_size=B, sr=sr, hipass_freq=0.0, cooldown=0)
