@@ -197,7 +197,10 @@ struct Cfg {
     // to 2048 points -- a 2048-point frame on 64 lanes (two butterflies per lane) synchronises its passes
     // inside the wave instead of with workgroup barriers across two waves
     static constexpr int T = (M / 8) < 16 ? 16 : ((M / 8) > 64 && F <= 2048 ? 64 : (M / 8));
-    static constexpr int WG = T > 256 ? T : 256;            // threads per workgroup
+    // threads per workgroup.  1024-point frames: 512 (eight frame slots) -- the tables a workgroup keeps in LDS
+    // (twiddles, window, filterbank, classifier) are then shared by eight waves instead of four, and two
+    // workgroups per CU are four waves per SIMD where three workgroups of 48 KB were three
+    static constexpr int WG = T > 256 ? T : (F == 1024 ? 512 : 256);
     static constexpr int FPW = WG / T;                      // frames per workgroup iteration
     // LDS: twM[M] + twF[M+1] (float2), window[F] (float), one buffer of M float2 per frame
     static constexpr int MP = FftBuf<M>::words;              // (padded) buffer of one frame (fft_pad)
