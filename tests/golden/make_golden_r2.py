@@ -12,6 +12,9 @@
                       (detection.py:800-825, `i` advanced before the loop at :813) executed by the reference
                       itself on top of a ring-buffer STAND-IN for the absent loopmate.CircularArray
                       (tests/golden/_refload.py) -- the loop bound therefore stays "parity unpinned".
+  g20_wide_dense      detect_onsets_amplitude on shapes the earlier sets do not reach: 64 channels at block 512
+                      (BASELINE config C3's shape), no cooldown at block 32, a long cooldown with absolute
+                      thresholds on 16 channels, a block size / rate that are multiples of nothing.
 Only inputs' recipes (seeded generators of onset_fingerprinting_amd.synth) and the reference's outputs are stored.
 """
 import sys
@@ -39,7 +42,7 @@ def save(name, **arrays):
     print(f"{name}: {path.stat().st_size / 1024:.1f} KiB")
 
 
-from make_golden_r2_cfg import G17_CASES, G18_CASES, RT  # noqa: E402
+from make_golden_r2_cfg import G17_CASES, G18_CASES, G20_CASES, RT  # noqa: E402
 
 
 def g17():
@@ -88,6 +91,20 @@ def g18():
         out[f"{name}_records"] = np.array(recs, dtype=np.int64).reshape(-1, 3)
         print(name, len(recs), "records,", plain, "moved by backtracking")
     save("g18_backtrack_py", **out)
+
+
+def g20():
+    out = {}
+    for name, (kw, C, secs, sr, B, rk) in G20_CASES.items():
+        x = synth.drum_hits(C, secs, sr, **rk)
+        out[f"{name}_xsum"] = x.astype(np.float64).sum()
+        c, o, rel = det.detect_onsets_amplitude(x, block_size=B, sr=sr, **kw)
+        out[f"{name}_ch"] = np.array(c, dtype=np.int64)
+        out[f"{name}_on"] = np.array(o, dtype=np.int64)
+        out[f"{name}_rel"] = rel[::97].copy()
+        out[f"{name}_relsum"] = rel.astype(np.float64).sum(axis=0)
+        print(name, len(c), "onsets", rel.shape)
+    save("g20_wide_dense", **out)
 
 
 def g19():
@@ -152,6 +169,7 @@ def g19():
 
 
 if __name__ == "__main__":
-    g17()
-    g18()
-    g19()
+    only = sys.argv[1:]  # e.g. `make_golden_r2.py g20` regenerates one set
+    for fn in (g17, g18, g19, g20):
+        if not only or fn.__name__ in only:
+            fn()

@@ -20,3 +20,15 @@ G18_CASES = {  # name -> (kwargs, C, B)
 # run has 4, the canon (oracle == GPU, bit for bit) 6, of which 1 in common -- 8 records differ; from sr on
 # all 54 are identical.  A change of these counts is a regression of the canon.
 RT_CHAOTIC = dict(below_sr_reference=4, below_sr_canon=6, below_sr_common=1, from_sr_on=54)
+
+# g20: shapes the earlier sets do not reach -- C3's 64 channels at block 512 (the cross-channel on_indices.max()
+# coupling with many channels firing in one block), no cooldown at block 32 (onsets in consecutive blocks), a long
+# cooldown, 16 channels with absolute thresholds.  name -> (kwargs, C, seconds, sr, block, synth recipe kwargs)
+G20_CASES = {
+    "wide64": (dict(), 64, 3.0, 48000, 512, dict(seed=201, period=0.23)),
+    "wide64_rt": (dict(hipass_freq=0, fast_ar=(3.0, 800.0), slow_ar=(8000.0, 8000.0), on_threshold=0.45, off_threshold=0.45),
+                  64, 2.0, 48000, 512, dict(seed=202, period=0.31)),
+    "dense8": (dict(cooldown=0, on_threshold=0.3, off_threshold=0.25), 8, 3.0, 48000, 32, dict(seed=203, period=0.05)),
+    "slow16": (dict(cooldown=9600, on_threshold=6.0, off_threshold=3.0), 16, 4.0, 48000, 256, dict(seed=204, period=0.11)),
+    "odd5": (dict(), 5, 3.0, 44100, 100, dict(seed=205, period=0.17)),
+}

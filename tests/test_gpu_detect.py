@@ -290,6 +290,19 @@ def test_g17_realtime_sets_on_the_gpu(det):
     assert np.array_equal(got, g["blk_records"])
 
 
+@pytest.mark.parametrize("tuning", [None, dict(lane_merge=1, hp_dedupe=1, hp_early=1, sm_segments=1)])
+def test_g20_wide_and_dense_shapes_on_the_gpu(det, tuning):
+    """g20 (64 channels at block 512, no cooldown at block 32, long cooldown with absolute thresholds, odd sizes):
+    GPU == the reference's golden indices, in the latency layout and in the throughput one."""
+    from tests.golden.make_golden_r2_cfg import G20_CASES
+    g = load_golden("g20_wide_dense")
+    for name, (kw, C, secs, sr, B, rk) in G20_CASES.items():
+        x = synth.drum_hits(C, secs, sr, **rk)
+        recs, rel, _ = det.detect_batch(x[None], tuning=tuning, block_size=B, sr=sr, **kw)
+        assert np.array_equal(recs[0]["channel"], g[f"{name}_ch"]) and np.array_equal(recs[0]["sample"], g[f"{name}_on"]), name
+        np.testing.assert_allclose(rel[0][::97], g[f"{name}_rel"], rtol=2e-5, atol=1e-6)
+
+
 def test_realtime_set_against_the_reference_golden_on_the_gpu(det):
     """fast_ar = (0.3, 800) on the g4 input: from the first second on the GPU's records equal the
     reference's golden rt_ch / rt_on; below it the documented, COUNTED deviation (RT_CHAOTIC)."""

@@ -308,6 +308,25 @@ def test_g17_realtime_sets_are_reproduced_exactly():
     assert np.array_equal(got, g["blk_records"]) and len(got) >= 20
 
 
+def test_g20_wide_and_dense_shapes_are_reproduced_exactly():
+    """Shapes the earlier sets do not reach, captured from the reference: 64 channels at block 512 (C3's shape: many
+    channels firing in one block, the cross-channel on_indices.max()), no cooldown at block 32 (onsets in consecutive
+    blocks), a long cooldown with absolute thresholds on 16 channels, a block size and rate that are multiples of
+    nothing.  Onset indices equal the reference's; the relative envelope within the float32 round-off of its
+    libm (the reference's log10 / power are the host's, ours the canon's)."""
+    from onset_fingerprinting_amd import synth
+    from tests.golden.make_golden_r2_cfg import G20_CASES
+    g = load_golden("g20_wide_dense")
+    for name, (kw, C, secs, sr, B, rk) in G20_CASES.items():
+        x = synth.drum_hits(C, secs, sr, **rk)
+        assert x.astype(np.float64).sum() == g[f"{name}_xsum"], "synthetic generator drifted"
+        c, o, rel = oracle.detect_onsets_amplitude(x, block_size=B, sr=sr, **kw)
+        assert np.array_equal(np.array(c), g[f"{name}_ch"]) and np.array_equal(np.array(o), g[f"{name}_on"]), name
+        assert len(c) >= 50
+        np.testing.assert_allclose(rel[::97], g[f"{name}_rel"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(rel.astype(np.float64).sum(axis=0), g[f"{name}_relsum"], rtol=1e-5)
+
+
 def test_realtime_set_deviation_is_counted():
     """fast_ar = (0.3, 800): rounding-chaotic below the first hit (tests/golden/make_golden_r2_cfg.py
     RT_CHAOTIC).  The count of differing records is pinned so that a change shows."""
