@@ -2930,7 +2930,6 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.dirty = reinterpret_cast<uint8_t*>(ws + l.o_mm_dirty);
         const int64_t nt = chains * l.mm_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
-        const unsigned grid = (unsigned)cdiv(nt, 64);
         {
             const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
             if (l.merge)
