@@ -53,3 +53,28 @@ def test_product_never_imports_the_oracle():
     for p in (REPO / "onset_fingerprinting_amd" / "csrc").glob("*"):
         if p.suffix in (".hip", ".h"):
             assert "oracle/" not in p.read_text(), p
+
+
+def test_struct_mirrors_follow_the_header_field_for_field():
+    """The ctypes mirrors of the header's structs list the same fields in the same order (a field added on one side
+    only shifts every later one silently)."""
+    from onset_fingerprinting_amd import _lib
+    src = (REPO / "include" / "onsetfp.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+    def fields(struct):
+        body = re.search(r"typedef struct " + struct + r"\s*\{(.*?)\}\s*" + struct + r"\s*;", src, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "int64_t a, b" / "const float* fb_w" / "float x"
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+            names += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
+        return names
+
+    assert fields("ofp_detect_tuning") == [f[0] for f in _lib.DetectTuning._fields_]
+    assert fields("ofp_hop_config") == [f[0] for f in _lib.HopConfig._fields_]
+    assert fields("ofp_detector_params") == [f[0] for f in _lib.DetectorParams._fields_]
