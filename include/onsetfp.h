@@ -40,7 +40,7 @@ extern "C" {
 #define OFP_ERR_WORKSPACE 4 /* caller-provided work space too small */
 #define OFP_ERR_NOCONVERGE 5 /* speculative time-parallel pass did not converge */
 
-#define OFP_ABI_VERSION 2
+#define OFP_ABI_VERSION 3
 
 /* ---- status ---------------------------------------------------------------- */
 int ofp_abi_version(void);
@@ -143,6 +143,12 @@ typedef struct ofp_detect_tuning {
                                     speculative passes is chosen for the GPU's share: with k calls in flight each
                                     gets 1/k of the lane budget, i.e. the work-efficient layout of a k times larger
                                     batch instead of the latency layout of a lone call.  Results do not change. */
+    int64_t host_verify;         /* who drives the verification passes of the three time-parallel stages: 0 (default)
+                                    chain-local kernels -- one workgroup owns whole chains and iterates its passes
+                                    between workgroup barriers until nothing changes: no host round trip, one launch per
+                                    stage, the call can be captured in a hipGraph; 1 the round-1/2 form: one launch per
+                                    pass, the host reads a change counter per group of passes (verify_group,
+                                    max_passes apply to this form only).  Results do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */
@@ -168,8 +174,9 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  *   d_counts   [n_clips] int64 number of onsets per clip (may exceed cap_per_clip:
  *              only cap_per_clip are stored)
  *   d_ws       work space of at least ofp_detect_workspace_bytes()
- * Synchronises `stream` internally (the speculative passes are verified on the
- * host); on return all outputs are complete.  h_info (optional, host, int64
+ * Synchronises `stream` ONCE, at its end (the speculative passes are verified on the device by
+ * chain-local kernels; tuning host_verify = 1 restores the host-verified pass groups of ABI 2); on return
+ * all outputs are complete.  h_info (optional, host, int64
  * [OFP_DETECT_INFO_LEN]) receives {0: hp passes, 1: follower passes, 2: tracker
  * passes, 3: repaired chunks, 4..9: nanoseconds (HIP events on `stream`) spent in
  * the hp, dB, follower, linear, tracker and crossing/state-machine stages,
@@ -177,12 +184,29 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  * longest single launch; or the stages k_hp_seg0 .. k_hp_seg_chunk), 12: IIR steps they execute
  * over all their lanes (17 fp32 operations each), 13: staged candidates only: distinct runs that
  * walked a chunk, of chains * chunks * candidates, 14: 1 if the segmented state machine did not converge within its
- * pre-enqueued passes and the sequential one decided}. */
+ * pre-enqueued passes and the sequential one decided, 15: non-zero if the call was repeated in its host-verified
+ * form (1, + 1: the pre-enqueued IIR rounds did not suffice, + 2 / + 4: a look-back wait of the follower / tracker
+ * stage gave up)}. */
 #define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
                        int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info,
                        void* stream);
+
+/* ofp_detect_offline without its synchronisation, in two calls.  _enqueue only ENQUEUES the whole call on `stream`
+ * (nothing in it blocks or reads a device result on the host: the stream may be capturing a hipGraph, and a captured
+ * graph may be replayed on new contents of the same buffers); after the caller has synchronised the stream (or the
+ * graph launch), _complete with the same arguments reads the few words the call left in pinned host memory, fills
+ * h_info (stage times only when the call was not captured) and, in the one case that needs a decision on the host --
+ * the segmented state machine of a long clip did not converge within its pre-enqueued passes (info 14; never observed)
+ * -- runs the sequential machine on `stream` and synchronises.  One enqueued call per detector at a time (it may be
+ * completed once per replay of a graph that captured it).  Not with tuning host_verify.  ofp_detect_offline == _enqueue + hipStreamSynchronize + _complete. */
+int ofp_detect_offline_enqueue(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                               int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
+                               int64_t* d_counts, void* d_ws, int64_t ws_bytes, void* stream);
+int ofp_detect_offline_complete(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                                int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
+                                int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream);
 
 /* The same call in two halves, so that a caller can overlap other work with the long, sparsely
  * occupied tail: _begin only ENQUEUES the head (input transpose + the IIR candidate launch, the
@@ -193,6 +217,11 @@ int ofp_detect_offline_begin(ofp_detector* det, const float* d_x, int64_t n_clip
 int ofp_detect_offline_finish(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                               int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
                               int64_t* d_counts, void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream);
+
+/* _finish without its synchronisation (complete it with ofp_detect_offline_complete after synchronising). */
+int ofp_detect_offline_finish_enqueue(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
+                                      int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,
+                                      int64_t* d_counts, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* _begin in two calls: _begin_input enqueues the planar copy of the input only (ofp_detect_planar_input
  * is valid once it has run), _begin_iir the IIR candidate launch. */

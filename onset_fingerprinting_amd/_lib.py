@@ -63,6 +63,7 @@ class DetectTuning(ctypes.Structure):
         ("fuse_db_sums", ctypes.c_int64),
         ("sm_segments", ctypes.c_int64),
         ("concurrent_calls", ctypes.c_int64),
+        ("host_verify", ctypes.c_int64),
     ]
 
 
@@ -112,6 +113,10 @@ SIGNATURES = {
     "ofp_detect_workspace_bytes": (_i64, [_vp, _i64, _i64, _i64]),
     "ofp_detect_offline": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
                                           ctypes.POINTER(_i64), _vp]),
+    "ofp_detect_offline_enqueue": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "ofp_detect_offline_complete": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
+                                                   ctypes.POINTER(_i64), _vp]),
+    "ofp_detect_offline_finish_enqueue": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "ofp_detect_offline_begin": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ofp_detect_offline_finish": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64,
                                                  ctypes.POINTER(_i64), _vp]),

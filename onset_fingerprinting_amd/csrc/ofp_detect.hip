@@ -548,8 +548,11 @@ __global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads
 __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_threads,
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
-                                                 int* changed) {
+                                                 int* changed, const int* gate) {
     OFP_LATENCY_BOUND_KERNEL();
+    // gate: the change counter of the pass this one follows (passes enqueued ahead of the host's knowledge): zero =
+    // that pass repaired nothing, so it left both end arrays identical and this pass has nothing to do
+    if (gate && *gate == 0) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -651,8 +654,9 @@ __global__ __launch_bounds__(64) void k_mm_warm2(MmArgs a, int64_t n_threads, ui
 __global__ __launch_bounds__(64) void k_mm_chunk(MmArgs a, int pass, int64_t n_threads,
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
-                                                 int* changed) {
+                                                 int* changed, const int* gate) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (gate && *gate == 0) return;  // (see k_ar_chunk)
     // launched with 2 * ceil(nt / 64) workgroups: the first half carries the max, the second the min
     const int64_t nt = a.n_chains * a.n_chunks;
     const int64_t half = (nt + 63) / 64;
@@ -739,8 +743,9 @@ __global__ __launch_bounds__(64) void k_mm_warm_both(MmArgs a, int64_t n_threads
 __global__ __launch_bounds__(64) void k_mm_chunk_both(MmArgs a, int pass, int64_t n_threads,
                                                       const uint32_t* __restrict__ end_prev,
                                                       uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
-                                                      int* changed) {
+                                                      int* changed, const int* gate) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (gate && *gate == 0) return;  // (see k_ar_chunk)
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -798,8 +803,9 @@ __global__ __launch_bounds__(64) void k_mm_chunk_both(MmArgs a, int pass, int64_
 // passes that follow run those again and remain the verification.
 __global__ __launch_bounds__(64) void k_mm_maxpass(MmArgs a, int64_t n_threads, const uint32_t* __restrict__ end_prev,
                                                    uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
-                                                   int* changed) {
+                                                   int* changed, const int* gate) {
     OFP_LATENCY_BOUND_KERNEL();
+    if (gate && *gate == 0) return;  // (see k_ar_chunk: a group of light passes runs only after a full pass that repaired)
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const int64_t k = id % a.n_chunks;
@@ -1145,20 +1151,25 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg_chunk(HpCand a, HpRu
     }
 }
 
-// pass B1: nxt[k][c][r_prev] for every chunk k >= 1 (parallel)
-__global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
-    OFP_LATENCY_BOUND_KERNEL();
-    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_items) return;
+// ---- verification of the candidates.  Three steps per round (k_hp_match / k_hp_resolve / k_hp_run), each step
+// written as a device function of ONE chain.  A round whose predecessor left nothing open returns at once
+// (HpCand::prev), so the host enqueues a fixed number of rounds ahead and reads the last round's counters with the
+// call's final synchronisation (tuning host_verify: a group of rounds per host round trip instead).
+// (A workgroup per chain running all rounds between barriers was measured as well: equal for big batches, but the
+// lone clip's stage takes 3.3 instead of 2.0 ms -- the run step's lanes then sit on 8 CUs instead of all.)
+
+// wave-scope synchronisation: the resolve step is the work of ONE wave, whose lanes exchange data through LDS and
+// global memory (inside a multi-wave workgroup a workgroup barrier would be wrong there)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// step B1: nxt[k][r_prev] = the slot of chunk k whose start state equals E[k-1][r_prev] (255: none)
+__device__ __forceinline__ void hp_match_item(const HpCand& a, int64_t clip, int c, int64_t k, int rp) {
     const int R1 = a.R + 1;
-    const int rp = (int)(id % R1);
-    int64_t q = id / R1;
     const int C = a.st.g.C;
-    const int c = (int)(q % C);
-    q /= C;
-    const int64_t k = q % a.st.n_chunks;
-    const int64_t clip = q / a.st.n_chunks;
     uint8_t res = 255;
     if (k > 0) {
         const uint32_t* e = a.E + a.slot(clip, k - 1, c, rp);
@@ -1171,22 +1182,32 @@ __global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
             }
         }
     }
-    // chain-major layout [clip][c][k][r]: the rows k0..k0+63 of one chain that k_hp_resolve stages
+    // chain-major layout [clip][c][k][r]: the rows k0..k0+63 of one chain that the resolve step stages
     // are contiguous bytes
     a.nxt[(((clip * C + c) * a.st.n_chunks + k) * R1) + rp] = res;
 }
 
-// pass A2 (once per call): gs[k] = the slot of chunk k whose END state is shared by the most
-// candidates (at least two), -1 if all end states differ.  Candidates that agree with each other
-// have merged, and then almost surely with the true trajectory as well: the guess k_hp_resolve
-// continues from at a break (and verifies afterwards).  16 lanes per chunk, lane r holds candidate r.
-__global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items) {
+__global__ __launch_bounds__(256) void k_hp_match(HpCand a, int64_t n_items) {
     OFP_LATENCY_BOUND_KERNEL();
-    const int64_t id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // (chain, k), k fastest
-    const int r = threadIdx.x & 15;
-    const bool live = id < n_items;
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_items) return;
+    const int R1 = a.R + 1;
+    const int rp = (int)(id % R1);
+    int64_t q = id / R1;
+    const int C = a.st.g.C;
+    const int c = (int)(q % C);
+    q /= C;
+    hp_match_item(a, q / a.st.n_chunks, c, q % a.st.n_chunks, rp);
+}
+
+// step A2 (once per call): gs[k] = the slot of chunk k whose END state is shared by the most
+// candidates (at least two), -1 if all end states differ.  Candidates that agree with each other
+// have merged, and then almost surely with the true trajectory as well: the guess the resolve step
+// continues from at a break (and verifies afterwards).  16 lanes per chunk, lane r holds candidate r
+// (every lane of a 16-lane group calls this, `live` or not: shuffles).
+__device__ __forceinline__ void hp_plurality_group(const HpCand& a, int64_t chain, int64_t k, bool live, int r) {
     const int64_t nk = a.st.n_chunks;
-    const int64_t k = live ? id % nk : 0, chain = live ? id / nk : 0;
     const int C = a.st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
@@ -1205,7 +1226,15 @@ __global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items)
     if (live && r == 0) a.gs[chain * nk + k] = (int8_t)(key < 0 ? -1 : 15 - (key & 15));
 }
 
-// pass B2: one wave per chain resolves which slot every chunk starts from.
+__global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // (chain, k), k fastest
+    const bool live = id < n_items;
+    const int64_t nk = a.st.n_chunks;
+    hp_plurality_group(a, live ? id / nk : 0, live ? id % nk : 0, live, threadIdx.x & 15);
+}
+
+// step B2: one wave per chain resolves which slot every chunk starts from.
 //
 // sel[k] = nxt[k][sel[k-1]]: a chain of table look-ups, i.e. a composition of maps
 // f_k : slot -> slot, which is associative -- so instead of walking the chain, each lane composes
@@ -1215,25 +1244,28 @@ __global__ __launch_bounds__(256) void k_hp_plurality(HpCand a, int64_t n_items)
 // A chunk k whose true start state E[k-1][sel] matches none of its candidates is a break: it has
 // to be run from that state before its end state is known, which costs a round.  Instead of
 // stopping there, f_k continues from the plurality end state of chunk k (gs[k]) and the chunk is
-// marked `guessed`; k_hp_run runs chunk k from its true start state in the same round (slot R),
+// marked `guessed`; the run step runs chunk k from its true start state in the same round (slot R),
 // and the NEXT resolve compares that exact end state with the guess.  Right (the usual case):
 // nothing else to do.  Wrong: slot R is selected, the later chunks of the chain are resolved again
 // and those whose start state actually changed are run again.  Without a plurality the chain is
 // stuck at k until the next round.  Results stay exact; only the number of rounds changes.
-__global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
-    OFP_LATENCY_BOUND_KERNEL();
-    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
-    constexpr int SEG = 8, RT = 64 * SEG;       // chunks per lane, per tile
-    constexpr int NV = HP_MAXR + 2, STUCK = HP_MAXR + 1;  // map domain: slots 0..R, STUCK
-    __shared__ uint8_t tile[RT * (HP_MAXR + 1)];
-    __shared__ int8_t stile[RT], rtile[RT], gtile[RT];
-    __shared__ uint8_t maps[2][64][NV];
+constexpr int HP_SEG = 8, HP_RT = 64 * HP_SEG;               // chunks per lane, per tile
+constexpr int HP_NV = HP_MAXR + 2, HP_STUCK = HP_MAXR + 1;   // map domain: slots 0..R, STUCK
+struct HpResolveLds {
+    uint8_t tile[HP_RT * (HP_MAXR + 1)];
+    int8_t stile[HP_RT], rtile[HP_RT], gtile[HP_RT];
+    uint8_t maps[2][64][HP_NV];
+};
+
+// -> bit 0: the chain is stuck at a break without a plurality, bit 1: it has unverified guesses (wave-uniform)
+__device__ __forceinline__ int hp_resolve_chain(const HpCand& a, int64_t chain, int lane, HpResolveLds& L) {
+    constexpr int SEG = HP_SEG, RT = HP_RT, NV = HP_NV, STUCK = HP_STUCK;
+    uint8_t* tile = L.tile;
+    int8_t *stile = L.stile, *rtile = L.rtile, *gtile = L.gtile;
     const int C = a.st.g.C, R1 = a.R + 1;
-    const int64_t chain = blockIdx.x;  // clip*C + c
     const int c = (int)(chain % C);
     const int64_t clip = chain / C;
     const int64_t nk = a.st.n_chunks;
-    const int lane = threadIdx.x;
     // --- verify the guesses of earlier rounds whose chunk has been run since
     int64_t wrong = nk;
     bool pending = false;
@@ -1266,7 +1298,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
         for (int64_t k = lane; k < wrong; k += 64) pending = pending || a.guessed[(clip * nk + k) * C + c];
         pending = __any(pending);
     }
-    __syncthreads();
+    wave_sync();
     // resume where the previous round stopped: chunks before pos[] are resolved
     const int64_t kstart = max<int64_t>(1, a.pos[chain]);
     int cur = a.sel[(clip * nk + kstart - 1) * C + c];  // slot chosen for the previous chunk
@@ -1281,7 +1313,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
     };
     for (int64_t k0 = kstart; k0 < nk && reached == nk; k0 += RT) {
         const int nblk = (int)min<int64_t>(RT, nk - k0);
-        __syncthreads();
+        wave_sync();
         {
             const uint8_t* src = a.nxt + ((clip * C + c) * nk + k0) * R1;  // nblk * R1 contiguous bytes
             for (int i = lane; i < nblk * R1; i += 64) tile[i] = src[i];
@@ -1291,25 +1323,25 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
             rtile[i] = a.ran[(clip * nk + k0 + i) * C + c];
             gtile[i] = a.gs[chain * nk + k0 + i];
         }
-        __syncthreads();
+        wave_sync();
         // 1. the map of this lane's segment [s0, s1)
         const int s0 = min(lane * SEG, nblk), s1 = min(s0 + SEG, nblk);
         for (int v = 0; v < NV; ++v) {
             int w = (v <= a.R || v == STUCK) ? v : STUCK;
             for (int i = s0; i < s1; ++i) w = step(i, w);
-            maps[0][lane][v] = (uint8_t)w;
+            L.maps[0][lane][v] = (uint8_t)w;
         }
-        __syncthreads();
+        wave_sync();
         // 2. inclusive scan over the lanes: maps[b][l] = segment 0 .. l composed
         int b = 0;
         for (int o = 1; o < 64; o <<= 1) {
             for (int v = 0; v < NV; ++v)
-                maps[b ^ 1][lane][v] = lane >= o ? maps[b][lane][maps[b][lane - o][v]] : maps[b][lane][v];
-            __syncthreads();
+                L.maps[b ^ 1][lane][v] = lane >= o ? L.maps[b][lane][L.maps[b][lane - o][v]] : L.maps[b][lane][v];
+            wave_sync();
             b ^= 1;
         }
         // 3. the slot entering this lane's segment, then the segment itself
-        int v = lane == 0 ? cur : maps[b][lane - 1][cur];
+        int v = lane == 0 ? cur : L.maps[b][lane - 1][cur];
         int first_stuck = RT;  // index in the tile of the chunk the chain is stuck at
         for (int i = s0; i < s1; ++i) {
             if (stile[i] >= 0) {
@@ -1348,46 +1380,52 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
         }
         for (int o = 32; o > 0; o >>= 1) first_stuck = min(first_stuck, __shfl_xor(first_stuck, o));
         if (first_stuck < RT) reached = k0 + first_stuck;
-        cur = maps[b][63][cur];  // the slot entering the next tile (meaningless once stuck)
+        cur = L.maps[b][63][cur];  // the slot entering the next tile (meaningless once stuck)
         pending = __any(pending);
     }
-    if (lane == 0) {
-        a.pos[chain] = (int32_t)reached;
-        if (reached < nk) atomicAdd(a.counters, 1);
-        if (pending) atomicAdd(a.counters + 1, 1);
+    if (lane == 0) a.pos[chain] = (int32_t)reached;
+    return (reached < nk ? 1 : 0) | (pending ? 2 : 0);
+}
+
+__global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
+    OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
+    __shared__ HpResolveLds L;
+    const int f = hp_resolve_chain(a, blockIdx.x, threadIdx.x, L);
+    if (threadIdx.x == 0) {
+        if (f & 1) atomicAdd(a.counters, 1);
+        if (f & 2) atomicAdd(a.counters + 1, 1);
     }
 }
 
-// pass C: run every chunk whose true start state is known and that has not produced its
+// step C: run every chunk whose true start state is known and that has not produced its
 // output yet, from that state; a chunk without a matching candidate fills slot R.
-// thread = (chain, chunk, sub-chunk).  A chunk whose start state matched candidate sel[] is run
+// item = (chain, chunk, sub-chunk).  A chunk whose start state matched candidate sel[] is run
 // by its S lanes in parallel, lane sb > 0 starting from that candidate's recorded inner state;
 // a chunk that starts from an unmatched state (a break, guessed or not) or whose own slot is the
 // exact re-run has no such states and is run whole by lane 0.
-__global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
-    OFP_LATENCY_BOUND_KERNEL();
-    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;
+// -> true if the item left sub-chunks open (an early stop): another round is needed
+__device__ __forceinline__ bool hp_run_item(const HpCand& a, int64_t chain, int64_t k, int sb) {
     const HpArgs& st = a.st;
-    const int sb = (int)(id % a.S);
-    const int64_t kc = id / a.S;
-    const int64_t k = kc % st.n_chunks;
-    const int64_t chain = kc / st.n_chunks;
     const int C = st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
     const int64_t ci = (clip * st.n_chunks + k) * C + c;
-    if (a.done[ci * a.S + sb]) return;
+    // >= 0: an earlier whole run joined candidate mg; its remaining sub-chunks are open.  Read BEFORE done[]: a whole
+    // run publishes done[] first and mrg last, so an item that sees the join also sees which sub-chunks it covered
+    // (the items of one chunk normally sit in one wave and read all of this before any of them walks; with a
+    // sub-chunk count that does not divide 64 they can straddle two)
+    const int mg = a.mrg[ci];
+    __threadfence();
+    if (a.done[ci * a.S + sb]) return false;
     int sp = 0;
     if (k > 0) {
         sp = a.sel[ci - C];
-        if (sp < 0) return;  // predecessor not resolved yet
+        if (sp < 0) return false;  // predecessor not resolved yet
     }
     const int own = a.sel[ci];
-    const int mg = a.mrg[ci];  // >= 0: an earlier whole run joined candidate mg; its remaining sub-chunks are open
     const bool whole = (own < 0 || own >= a.R || a.guessed[ci]) && mg < 0;  // no exact inner states
-    if (whole && sb > 0) return;
+    if (whole && sb > 0) return false;
     HpStep s;
     s.coeffs(st.b, st.a);
     uint32_t xin[4] = {0u, 0u, 0u, 0u};
@@ -1405,26 +1443,21 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t start = k * st.L;
     const int64_t end = min(start + st.L, st.g.V);
     const int64_t Ls = st.L / a.S;
-    if (!whole) {
-        const int64_t t0 = min(start + sb * Ls, end);
-        const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
-        hp_span<true>(st, s, chain, t0, t1);
-        if (sb == 0) a.ran[ci] = (int8_t)own;
-        a.done[ci * a.S + sb] = 1;
-        return;
-    }
-    // A whole run from the true start state.  With `early` it stops at the first sub-chunk boundary where its
-    // state equals (bitwise) the state some candidate recorded there: from that point on it IS that candidate's
-    // trajectory, so the chunk's end state is known at once (E of that candidate) and the sub-chunks behind the
-    // boundary are left to the lanes of the next round, which start from the candidate's inner states.
-    const int nq = a.early ? a.S : 1;
+    // One walk call site for both kinds of item (a second instantiation of the unrolled loop doubles the kernel):
+    // a verified sub-chunk is the single piece [sb], a whole run the pieces 0 .. S-1 (or ONE piece [start, end)
+    // without `early`).  With `early` a whole run stops at the first sub-chunk boundary where its state equals
+    // (bitwise) the state some candidate recorded there: from that point on it IS that candidate's trajectory, so
+    // the chunk's end state is known at once (E of that candidate) and the sub-chunks behind the boundary are left
+    // to the lanes of the next round, which start from the candidate's inner states.
+    const bool pieces = !whole || a.early;
+    const int q0 = whole ? 0 : sb, q1 = !whole ? sb + 1 : (a.early ? a.S : 1);
     int joined = -1, n_done = a.S;
 #pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
-        const int64_t t0 = nq == 1 ? start : min(start + q * Ls, end);
-        const int64_t t1 = (nq == 1 || q == nq - 1) ? end : min(start + (q + 1) * Ls, end);
+    for (int q = q0; q < q1; ++q) {
+        const int64_t t0 = pieces ? min(start + q * Ls, end) : start;
+        const int64_t t1 = (!pieces || q == a.S - 1) ? end : min(start + (q + 1) * Ls, end);
         hp_span<true>(st, s, chain, t0, t1);
-        if (q + 1 < nq) {
+        if (whole && q + 1 < q1) {
             const uint32_t z0 = ofp_f2u(s.z[0]), z1 = ofp_f2u(s.z[1]), z2 = ofp_f2u(s.z[2]), z3 = ofp_f2u(s.z[3]);
             for (int r = 0; r < a.R; ++r) {
                 if (a.U[a.slot(clip, k, c, r)] == 0x7fc00001u) continue;  // a slot no run filled: no records
@@ -1440,10 +1473,15 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
             }
         }
     }
+    if (!whole) {
+        if (sb == 0) a.ran[ci] = (int8_t)own;
+        a.done[ci * a.S + sb] = 1;
+        return false;
+    }
     if (own < 0 || a.guessed[ci]) {
         // no candidate matched: this exact run becomes slot R.  sel[ci] itself is NOT written
         // here (a successor running in this same launch must not see a half-filled slot); the
-        // next k_hp_match finds slot R and k_hp_resolve selects it (or, for a guessed chunk,
+        // next match step finds slot R and the resolve step selects it (or, for a guessed chunk,
         // compares it with the guess).
         uint32_t* u = a.U + a.slot(clip, k, c, a.R);
         uint32_t* e = a.E + a.slot(clip, k, c, a.R);
@@ -1455,9 +1493,20 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
         }
     }
     a.ran[ci] = (int8_t)a.R;
-    a.mrg[ci] = (int8_t)joined;
     for (int q = 0; q < n_done; ++q) a.done[ci * a.S + q] = 1;
-    if (joined >= 0) atomicAdd(a.counters + 1, 1);  // open sub-chunks: the host must enqueue another round
+    __threadfence();
+    a.mrg[ci] = (int8_t)joined;
+    return joined >= 0;  // open sub-chunks: another round
+}
+
+__global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
+    OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int sb = (int)(id % a.S);
+    const int64_t kc = id / a.S;
+    if (hp_run_item(a, kc / a.st.n_chunks, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
 }
 
 // ---- elementwise stages (planar, in place) -------------------------------------------
@@ -2245,6 +2294,8 @@ __global__ __launch_bounds__(64) void k_backtrack(BtArgs a) {
 
 // ---------------------------------------------------------------------------
 // host side
+constexpr int HP_MAX_ROUNDS = 16;     // IIR verification rounds enqueued ahead, at most
+constexpr int AHEAD_MAX_PASSES = 24;  // follower / tracker: verifying passes enqueued ahead, at most (light groups count as one)
 constexpr int OFP_N_COUNTERS = 512;  // int slots at the head of the zeroed region
 
 struct Layout {
@@ -2261,7 +2312,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks, mm_S;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty, o_hp_rounds, o_pass_flags,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_vtile, o_ltile, o_smseg, o_flags, o_zero, zero_bytes, total;
 };
 
@@ -2448,6 +2499,8 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_hp_pos = take(n_clips * g.C * 4);
     l.o_hp_stage_n = take(16 * 4);  // runs left after each dedupe of the staged candidates
     l.o_mm_dirty = take(n_clips * l.mm_chunks * g.C);
+    l.o_hp_rounds = take(2 * HP_MAX_ROUNDS * 4);  // IIR stage: {stuck, pending} of every round enqueued ahead
+    l.o_pass_flags = take(2 * AHEAD_MAX_PASSES * 4);  // follower / tracker stage: change counter of every pass enqueued ahead
     l.o_vflag = take(n_clips * l.nb * 4);
     l.zero_bytes = o - l.o_zero;
     l.total = o;
@@ -2478,7 +2531,7 @@ template <class K, class A>
 int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
                Counters& ctr, int* h_flags, int max_passes, int group, hipStream_t stream, int64_t* passes,
                int64_t* repaired,
-               void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, hipStream_t) = nullptr,
+               void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, const int*, hipStream_t) = nullptr,
                int64_t words = 0) {
     if (words == 0) words = n_threads * 2;  // state words per array
     uint32_t* endA = used + words;
@@ -2486,7 +2539,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
     const unsigned grid = (unsigned)cdiv(n_threads, 64);
     int* d_changed = ctr.base;  // pass 0 counts nothing
     hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
-                       d_changed);
+                       d_changed, (const int*)nullptr);
     OFP_LAUNCH_CHECK(name);
     *passes = 1;
     if (n_chunks == 1) return OFP_OK;  // a single chunk starts from the true state: exact
@@ -2500,7 +2553,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
         if (int rc = ctr.take(group, &d_changed)) return rc;
         for (int q = 0; q < group; ++q) {
             hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass + q, n_threads, (const uint32_t*)prev,
-                               next, used, d_changed + q);
+                               next, used, d_changed + q, (const int*)nullptr);
             std::swap(prev, next);
         }
         OFP_LAUNCH_CHECK(name);
@@ -2521,7 +2574,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
             for (int grp = 0; grp < 4096; ++grp) {
                 if (int rc = ctr.take(1, &d_changed)) return rc;
                 for (int q = 0; q < 8; ++q) {
-                    light_pass(args, n_threads, prev, next, used, d_changed, stream);
+                    light_pass(args, n_threads, prev, next, used, d_changed, nullptr, stream);
                     std::swap(prev, next);
                 }
                 OFP_LAUNCH_CHECK(name);
@@ -2532,6 +2585,43 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
             }
         }
     }
+    return OFP_OK;
+}
+
+// The same stage with NO host round trip (the default since round 3): pass 0 and `nv` verifying passes are enqueued
+// ahead; every pass after the first verifying one is gated on the change counter of the pass it follows -- zero: that
+// pass repaired nothing (and left both end arrays identical), so this one returns at once.  With `light_pass`, a group
+// of eight light passes follows every second verifying pass, gated on it likewise.  flags[j-1] = chunks pass j
+// repaired; the stage has converged iff flags[nv-1] == 0, which the host reads with the call's final synchronisation
+// (not converged: the call is repeated in the host-verified form above).  flags: 2 * nv zeroed ints.
+template <class K, class A>
+int run_jacobi_ahead(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
+                     int* flags, int nv, hipStream_t stream,
+                     void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, const int*, hipStream_t) = nullptr,
+                     int64_t words = 0) {
+    if (words == 0) words = n_threads * 2;
+    uint32_t* endA = used + words;
+    uint32_t* endB = endA + words;
+    const unsigned grid = (unsigned)cdiv(n_threads, 64);
+    hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
+                       flags, (const int*)nullptr);
+    uint32_t* prev = endA;
+    uint32_t* next = endB;
+    if (n_chunks > 1) {
+        for (int j = 1; j <= nv; ++j) {
+            const int* gate = j > 1 ? flags + j - 2 : nullptr;
+            hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, j, n_threads, (const uint32_t*)prev, next, used,
+                               flags + j - 1, gate);
+            std::swap(prev, next);
+            if (light_pass && j % 2 == 0 && j < nv) {
+                for (int q = 0; q < 8; ++q) {
+                    light_pass(args, n_threads, prev, next, used, flags + nv + j - 1, flags + j - 1, stream);
+                    std::swap(prev, next);
+                }
+            }
+        }
+    }
+    OFP_LAUNCH_CHECK(name);
     return OFP_OK;
 }
 
@@ -2575,7 +2665,7 @@ int ofp_detector_create(const ofp_detector_params* p, const double* on_threshold
     if (e == hipSuccess) e = hipMemcpy(d->d_off_f, offf.data(), C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_on_d, d->on.data(), C * sizeof(double), hipMemcpyHostToDevice);
     for (int k = 0; k < 10 && e == hipSuccess; ++k) e = hipEventCreate(&d->ev[k]);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_flags, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_flags, 1024, hipHostMallocDefault);
     if (e == hipSuccess) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -2645,10 +2735,13 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64
 
 // phase 0: everything; phase 1: only the asynchronous head (transpose + candidates launch);
 // phase 2: everything after the head (the caller ran phase 1 with the same arguments);
-// phase 5 + phase 6: phase 1 in two calls, the planar input copy / the IIR candidate launch
+// phase 5 + phase 6: phase 1 in two calls, the planar input copy / the IIR candidate launch;
+// phase 7: completion of a call that was only enqueued (run_mode 1), after the caller has synchronised.
+// run_mode 0: enqueue, synchronise, complete; 1: enqueue only (phases 0 and 2; nothing in it blocks or reads
+// device results on the host, so the stream may be capturing a hipGraph).
 static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
                        float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts,
-                       void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_, int phase) {
+                       void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_, int phase, int run_mode = 0) {
     OFP_REQUIRE(d && d_counts && d_ws, "ofp_detect_offline: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && N >= 0 && cap >= 0, "ofp_detect_offline: bad sizes");
     OFP_REQUIRE(d_x || N == 0, "ofp_detect_offline: d_x is NULL");
@@ -2661,21 +2754,43 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                          (long long)l.total);
     const Geom& g = l.g;
     const auto& p = d->p;
+    const bool host_verify = d->t.host_verify == 1;   // (2 / 3, experiments: the IIR stage only / the followers and the tracker only)
+    const bool hv_hp = host_verify || d->t.host_verify == 2, hv_fm = host_verify || d->t.host_verify == 3;
+    const bool enqueue_only = run_mode == 1;
+    OFP_REQUIRE(!(enqueue_only && d->t.host_verify > 0), "ofp_detect_offline_enqueue: not with tuning host_verify (its passes are "
+                "verified on the host)");
     unsigned char* ws = static_cast<unsigned char*>(d_ws);
     float* xt = reinterpret_cast<float*>(ws + l.o_xt);
     float* xdb = reinterpret_cast<float*>(ws + l.o_xdb);
     float* dif = reinterpret_cast<float*>(ws + l.o_dif);
     Counters ctr{reinterpret_cast<int*>(ws + l.o_flags), 0, stream};
+    int* pass_flags = reinterpret_cast<int*>(ws + l.o_pass_flags);  // follower passes at 0, tracker passes at AHEAD_MAX_PASSES
+    ofp_detect_pending& pend = d->pend;
     int64_t info[OFP_DETECT_INFO_LEN] = {0};
     hipEvent_t* ev = d->ev;
     const bool do_head = phase == 0 || phase == 1 || phase == 5;   // zero fill + transpose
     const bool do_cand = phase == 0 || phase == 1 || phase == 6;   // the IIR candidate launch
-    if (do_head) OFP_HIP(hipEventRecord(ev[0], stream));
-    bool hp_cand_timed = false;
+    // stage timing by HIP events -- not while the stream is capturing (an event recorded into a graph has no time)
+    bool timed = true;
+    if (phase != 7) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) timed = false;
+        if (!timed) OFP_REQUIRE(enqueue_only || phase == 1 || phase == 5 || phase == 6,
+                                "ofp_detect_offline: the stream is capturing; use ofp_detect_offline_enqueue");
+        if (do_head) pend.timed = timed;
+        else timed = timed && pend.timed;
+    }
+    if (do_head && timed) OFP_HIP(hipEventRecord(ev[0], stream));
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
         if (phase == 1 || phase == 5 || phase == 6) return OFP_OK;
-        OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
-        OFP_HIP(hipStreamSynchronize(stream));
+        if (phase != 7) OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
+        if (enqueue_only) {
+            pend.valid = true;
+            pend.empty = true;
+            return OFP_OK;
+        }
+        if (phase != 7) OFP_HIP(hipStreamSynchronize(stream));
+        pend.valid = false;
         if (h_info) std::memcpy(h_info, info, sizeof(info));
         return OFP_OK;
     }
@@ -2683,6 +2798,149 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const int64_t n_elem = chains * g.U;
     const unsigned ew_grid = (unsigned)std::min<int64_t>(cdiv(n_elem, 256), 256 * 16);
     const size_t tile_lds = (size_t)g.C * (l.tu + 1) * sizeof(float);
+    const float* rel = dif;  // (the relative envelope overwrites the follower difference in place)
+
+    // --- the last stage's arguments, needed by the completion as well (sequential machine as the fall-back)
+    int32_t* va_nv = reinterpret_cast<int32_t*>(ws + l.o_nv);
+    SmArgs sm;
+    sm.g = g;
+    sm.nb = l.nb;
+    sm.n_clips = n_clips;
+    sm.cap = cap;
+    sm.cooldown = p.cooldown;
+    sm.vis_j = reinterpret_cast<int32_t*>(ws + l.o_visj);
+    sm.vfc = reinterpret_cast<int32_t*>(ws + l.o_vrec);
+    sm.vlb = sm.vfc + n_clips * l.nb * g.C;
+    sm.vpc = sm.vlb + n_clips * l.nb * g.C;
+    sm.nv = va_nv;
+    sm.records = d_records;
+    sm.counts = d_counts;
+    sm.clip_base = 0;
+    auto sequential_machine = [&]() -> int {
+        const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
+        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)3 * tb * g.C * 4 + 64 * 4 + 16;
+        if (lds > 65536)
+            OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_state_machine),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
+        OFP_LAUNCH_CHECK("k_state_machine");
+        return OFP_OK;
+    };
+    auto backtrack = [&]() -> int {
+        if (!(p.backtrack && cap > 0)) return OFP_OK;
+        BtArgs bt;
+        bt.g = g;
+        bt.rel = rel;
+        bt.records = d_records;
+        bt.counts = d_counts;
+        bt.cap = cap;
+        bt.n_clips = n_clips;
+        bt.N = p.backtrack_buffer_size;
+        bt.alpha = p.backtrack_alpha;
+        bt.tol = p.backtrack_tol;
+        hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
+        OFP_LAUNCH_CHECK("k_backtrack");
+        return OFP_OK;
+    };
+    // after the final synchronisation: the segmented machine's verdict, the pass statistics, the stage times
+    auto complete = [&]() -> int {
+        // (pend stays valid: a graph that captured the enqueued call may be replayed and completed any number of times)
+        std::memcpy(info, pend.info, sizeof(info));
+        if (pend.sm_flag && (d->h_flags[40] != 0 || d->t.sm_segments == 2)) {  // (2: tests exercise this path)
+            // the last verification pass still changed a segment's start state (a machine that does not forget within
+            // four segments): the sequential machine decides
+            if (int rc = sequential_machine()) return rc;
+            if (int rc = backtrack()) return rc;
+            if (pend.timed) OFP_HIP(hipEventRecord(ev[6], stream));
+            OFP_HIP(hipStreamSynchronize(stream));
+            info[14] = 1;
+        }
+        {
+            const int* pf = d->h_flags + 96;   // change counters of the follower (0..) / tracker (AHEAD_MAX_PASSES..) passes
+            const int* hr = d->h_flags + 64;   // {stuck, pending} per enqueued IIR round
+            bool hp_open = false, ar_err = false, mm_err = false;
+            if (pend.hp_rounds > 0) {  // (0: no high-pass, or its rounds were verified on the host)
+                int used_rounds = 1;
+                while (used_rounds < pend.hp_rounds && hr[2 * (used_rounds - 1)] + hr[2 * (used_rounds - 1) + 1] != 0) ++used_rounds;
+                for (int q = 0; q < used_rounds; ++q) info[3] += hr[2 * q] + hr[2 * q + 1];
+                hp_open = hr[2 * (pend.hp_rounds - 1)] + hr[2 * (pend.hp_rounds - 1) + 1] != 0;
+                // the next call enqueues what this one needed plus a margin (decaying slowly)
+                d->hp_rounds_hint = std::max(used_rounds + 2, d->hp_rounds_hint - 1);
+                info[0] = used_rounds;
+            }
+            if (pend.ahead) {
+                // passes that ran: pass 0, the first verifying one, and every further one whose predecessor repaired
+                auto ran = [&](const int* f, int nv, int* hint, int64_t* passes) -> bool {
+                    if (nv == 0) {
+                        *passes = 1;
+                        return false;
+                    }
+                    int used_v = 1;
+                    while (used_v < nv && f[used_v - 1] != 0) ++used_v;
+                    for (int j = 0; j < used_v; ++j) info[3] += f[j];
+                    for (int j = nv; j < 2 * nv; ++j) info[3] += f[j];  // (the light groups)
+                    *passes = 1 + used_v;
+                    *hint = std::max(used_v + 1, *hint - 1);
+                    return f[nv - 1] != 0;
+                };
+                ar_err = ran(pf, pend.ar_nv, &d->ar_pass_hint, &info[1]);
+                mm_err = ran(pf + AHEAD_MAX_PASSES, pend.mm_nv, &d->mm_pass_hint, &info[2]);
+                if (p.manual) info[2] = 0;
+            }
+            if (hp_open || ar_err || mm_err || d->t.host_verify == -2) {  // (-2: tests exercise this path)
+                // the pre-enqueued IIR rounds did not suffice (or a look-back wait gave up): the whole call again,
+                // its passes verified on the host
+                const ofp_detect_tuning keep = d->t;
+                const ofp_detect_pending keep_pend = pend;  // (a graph that captured this call may be replayed again)
+                d->t.host_verify = 1;
+                if (hp_open) d->hp_rounds_hint = std::min(HP_MAX_ROUNDS, 2 * pend.hp_rounds);
+                if (ar_err) d->ar_pass_hint = std::min(AHEAD_MAX_PASSES / 2, 2 * pend.ar_nv);
+                if (mm_err) d->mm_pass_hint = std::min(AHEAD_MAX_PASSES / 2, 2 * pend.mm_nv);
+                const int rc = detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info,
+                                           stream_, 0, 0);
+                d->t = keep;
+                d->pend = keep_pend;
+                if (rc == OFP_OK && h_info) h_info[15] = 1 + (hp_open ? 1 : 0) + (ar_err ? 2 : 0) + (mm_err ? 4 : 0);  // (see include/onsetfp.h)
+                return rc;
+            }
+        }
+        if (pend.staged) {  // distinct runs that walked each later segment / the chunk (slightly over: clamped windows)
+            const int* n = d->h_flags + 16;
+            for (int m = 0; m + 1 < pend.n_cuts; ++m) info[12] += (int64_t)n[m] * (pend.cuts[m + 1] - pend.cuts[m]);
+            info[12] += (int64_t)n[pend.n_cuts - 1] * l.hp_L;
+            info[13] = n[pend.n_cuts - 1];  // runs that walked a chunk (of chains * chunks * R candidates)
+        }
+        if (pend.timed) {  // stage durations in nanoseconds (HIP events on the launch stream)
+            for (int k = 0; k < 6; ++k) {
+                float ms = 0.0f;
+                OFP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+                info[4 + k] = (int64_t)(ms * 1.0e6);
+            }
+            float ms = 0.0f;
+            OFP_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
+            info[10] = (int64_t)(ms * 1.0e6);
+            if (pend.hp_timed) {  // the IIR candidate launch(es)
+                OFP_HIP(hipEventElapsedTime(&ms, ev[8], ev[7]));
+                info[11] = (int64_t)(ms * 1.0e6);
+            }
+        }
+        if (h_info) std::memcpy(h_info, info, sizeof(info));
+        return OFP_OK;
+    };
+    if (phase == 7) {
+        OFP_REQUIRE(pend.valid, "ofp_detect_offline_complete: no enqueued call is pending on this detector");
+        if (pend.empty) {
+            if (h_info) std::memcpy(h_info, info, sizeof(info));
+            return OFP_OK;
+        }
+        return complete();
+    }
+    if (do_head) {
+        pend.hp_timed = false;
+        pend.staged = false;
+        pend.empty = false;
+        std::memset(pend.info, 0, sizeof(pend.info));
+    }
 
     // --- transpose in
     if (do_head) {
@@ -2690,7 +2948,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
                            stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
         OFP_LAUNCH_CHECK("k_transpose_in");
-        OFP_HIP(hipEventRecord(ev[8], stream));
+        if (timed) OFP_HIP(hipEventRecord(ev[8], stream));
     }
     if (phase == 5) return OFP_OK;
 
@@ -2724,7 +2982,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hc.pos = reinterpret_cast<int32_t*>(ws + l.o_hp_pos);
         hc.probe = nullptr;
         hc.prev = nullptr;
-        const char* probe_path = do_cand ? getenv("OFP_HP_PROBE") : nullptr;
+        const char* probe_path = (do_cand && timed) ? getenv("OFP_HP_PROBE") : nullptr;
         const int64_t probe_waves = cdiv(chains * l.hp_chunks * (l.hp_R / l.hp_span), 64);
         if (probe_path) OFP_HIP(hipMalloc(&hc.probe, probe_waves * 32));
         const int64_t nA = chains * l.hp_chunks * (hc.R / hc.span);
@@ -2772,7 +3030,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                                        (const int*)(stage_n + m));
             }
             OFP_LAUNCH_CHECK("k_hp_dedupe / k_hp_seg / k_hp_seg_chunk");
-            OFP_HIP(hipEventRecord(ev[7], stream));
+            if (timed) OFP_HIP(hipEventRecord(ev[7], stream));
         } else if (do_cand) {
             const unsigned cand_grid = (unsigned)cdiv(nA, HP_CAND_THREADS);
             if ((int64_t)cand_grid <= d->n_cus && d->t.concurrent_calls <= 1)
@@ -2780,7 +3038,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             else
                 hipLaunchKernelGGL(k_hp_candidates<false>, dim3(cand_grid), dim3(HP_CAND_THREADS), 0, stream, hc, nA);
             OFP_LAUNCH_CHECK("k_hp_candidates");
-            OFP_HIP(hipEventRecord(ev[7], stream));
+            if (timed) OFP_HIP(hipEventRecord(ev[7], stream));
             if (hc.probe) {  // diagnostics: where and when every wave of the launch ran (tools/wave_placement.py)
                 std::vector<unsigned long long> h(probe_waves * 4);
                 OFP_HIP(hipStreamSynchronize(stream));
@@ -2794,72 +3052,94 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 }
             }
         }
-        hp_cand_timed = true;
-        if (l.hp_staged) {  // stage 0 here; the later stages once their run counts are on the host (below)
+        if (do_cand) {
+            pend.hp_timed = timed;
+            pend.staged = l.hp_staged;
+            pend.n_cuts = n_cuts;
+            std::memcpy(pend.cuts, cuts, sizeof(cuts));
             int64_t steps = 0;
-            for (int64_t j = 0; j < l.hp_chunks; ++j)
-                for (int r = 0; r < hc.R; ++r)
-                    steps += std::max<int64_t>(j * l.hp_L - l.hp_W + cuts[0], 0) -
-                             std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
-            info[12] = steps * chains;
-        } else {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
-            int64_t steps = 0;
-            const int Rm = hc.R / hc.span;
-            for (int64_t j = 0; j < l.hp_chunks; ++j) {
-                const int64_t run_end = std::min<int64_t>((j + hc.span) * l.hp_L, g.V);
-                for (int r = 0; r < Rm; ++r)
-                    steps += run_end - std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
+            if (l.hp_staged) {  // stage 0 here; the later stages once their run counts are on the host (completion)
+                for (int64_t j = 0; j < l.hp_chunks; ++j)
+                    for (int r = 0; r < hc.R; ++r)
+                        steps += std::max<int64_t>(j * l.hp_L - l.hp_W + cuts[0], 0) -
+                                 std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
+            } else {  // IIR steps this launch executes over all its lanes (the speculation's redundant work)
+                const int Rm = hc.R / hc.span;
+                for (int64_t j = 0; j < l.hp_chunks; ++j) {
+                    const int64_t run_end = std::min<int64_t>((j + hc.span) * l.hp_L, g.V);
+                    for (int r = 0; r < Rm; ++r)
+                        steps += run_end - std::max<int64_t>(j * l.hp_L - l.hp_W - r * hc.delta, 0);
+                }
             }
-            info[12] = steps * chains;
+            pend.info[12] = steps * chains;
         }
         if (phase == 1 || phase == 6) return OFP_OK;
-        hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
-        OFP_LAUNCH_CHECK("k_hp_plurality");
-        // Verification rounds are enqueued a group at a time (three, then two) with ONE host synchronisation
-        // per group; a round whose predecessor left nothing unresolved returns at once (HpCand::prev).
         if (l.hp_staged)
             OFP_HIP(hipMemcpyAsync(d->h_flags + 16, stage_n, 16 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        const int* last = nullptr;
-        for (int it = 0;;) {
-            const int G = d->t.verify_group > 0 ? (int)std::min<int64_t>(d->t.verify_group, 8) : (it == 0 ? 3 : 2);
-            int* c = nullptr;
-            if (int rc = ctr.take(2 * G, &c)) return rc;
-            // (a call that needs hundreds of rounds recycles the last counter slots, which are zeroed again: the
-            //  previous round's counters may be among them and would then read "nothing left" -- no skip check then)
-            if (c == ctr.base + OFP_N_COUNTERS - 16) last = nullptr;
-            for (int q = 0; q < G; ++q) {
+        if (!hv_hp) {
+            // A fixed number of rounds enqueued ahead, no host round trip: a round whose predecessor left nothing
+            // open returns at once (a few microseconds).  The count follows what the detector's recent calls needed
+            // (+2); the last round's counters are read with the final synchronisation, and a call that has not
+            // converged by then (never seen with the margin) is repeated in the host-verified form.
+            hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
+            OFP_LAUNCH_CHECK("k_hp_plurality");
+            const int NR = std::max(3, std::min(HP_MAX_ROUNDS, d->hp_rounds_hint));
+            int* c = reinterpret_cast<int*>(ws + l.o_hp_rounds);
+            for (int q = 0; q < NR; ++q) {
                 hc.counters = c + 2 * q;
-                hc.prev = last;
+                hc.prev = q > 0 ? c + 2 * (q - 1) : nullptr;
                 hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
                 hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
                 hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
-                last = hc.counters;
             }
             OFP_LAUNCH_CHECK("k_hp_match / k_hp_resolve / k_hp_run");
-            int* flags = d->h_flags;  // per round: chains stuck at a break, chains with unverified guesses
-            OFP_HIP(hipMemcpyAsync(flags, c, 2 * G * sizeof(int), hipMemcpyDeviceToHost, stream));
-            OFP_HIP(hipStreamSynchronize(stream));
-            int stuck = 0;
-            for (int q = 0; q < G; ++q) {
-                stuck = flags[2 * q] + flags[2 * q + 1];
-                info[0] += 1;
-                info[3] += stuck;
+            pend.hp_rounds = NR;
+            OFP_HIP(hipMemcpyAsync(d->h_flags + 64, c, 2 * NR * sizeof(int), hipMemcpyDeviceToHost, stream));
+        } else {
+            hipLaunchKernelGGL(k_hp_plurality, dim3((unsigned)cdiv(nC0 * 16, 256)), dim3(256), 0, stream, hc, nC0);
+            OFP_LAUNCH_CHECK("k_hp_plurality");
+            // Verification rounds are enqueued a group at a time (three, then two) with ONE host synchronisation
+            // per group; a round whose predecessor left nothing unresolved returns at once (HpCand::prev).
+            const int* last = nullptr;
+            for (int it = 0;;) {
+                const int G = d->t.verify_group > 0 ? (int)std::min<int64_t>(d->t.verify_group, 8) : (it == 0 ? 3 : 2);
+                int* c = nullptr;
+                if (int rc = ctr.take(2 * G, &c)) return rc;
+                // (a call that needs hundreds of rounds recycles the last counter slots, which are zeroed again: the
+                //  previous round's counters may be among them and would then read "nothing left" -- no skip check then)
+                if (c == ctr.base + OFP_N_COUNTERS - 16) last = nullptr;
+                for (int q = 0; q < G; ++q) {
+                    hc.counters = c + 2 * q;
+                    hc.prev = last;
+                    hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
+                    hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
+                    hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
+                    last = hc.counters;
+                }
+                OFP_LAUNCH_CHECK("k_hp_match / k_hp_resolve / k_hp_run");
+                int* flags = d->h_flags;  // per round: chains stuck at a break, chains with unverified guesses
+                OFP_HIP(hipMemcpyAsync(flags, c, 2 * G * sizeof(int), hipMemcpyDeviceToHost, stream));
+                OFP_HIP(hipStreamSynchronize(stream));
+                int stuck = 0;
+                for (int q = 0; q < G; ++q) {
+                    stuck = flags[2 * q] + flags[2 * q + 1];
+                    pend.info[0] += 1;
+                    pend.info[3] += stuck;
+                    if (stuck == 0) break;
+                }
+                it += G;
                 if (stuck == 0) break;
+                if (d->t.max_passes > 0 && it > d->t.max_passes)
+                    return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
             }
-            it += G;
-            if (stuck == 0) break;
-            if (d->t.max_passes > 0 && it > d->t.max_passes)
-                return ofp::fail(OFP_ERR_NOCONVERGE, "hp stage: %d chains still unresolved after %d rounds", stuck, it);
-        }
-        if (l.hp_staged) {  // distinct runs that walked each later segment / the chunk (slightly over: clamped windows)
-            const int* n = d->h_flags + 16;
-            for (int m = 0; m + 1 < n_cuts; ++m) info[12] += (int64_t)n[m] * (cuts[m + 1] - cuts[m]);
-            info[12] += (int64_t)n[n_cuts - 1] * l.hp_L;
-            info[13] = n[n_cuts - 1];  // runs that walked a chunk (of chains * chunks * R candidates)
         }
     }
     if (phase == 1 || phase == 6) return OFP_OK;  // (no high-pass: the head is the transpose alone)
-    OFP_HIP(hipEventRecord(ev[1], stream));
+    pend.ahead = !hv_fm;
+    if (hv_fm || p.manual) pend.mm_nv = 0;
+    if (hv_fm) pend.ar_nv = 0;
+    if (!p.hp_enabled || hv_hp) pend.hp_rounds = 0;
+    if (timed) OFP_HIP(hipEventRecord(ev[1], stream));
     ArArgs a;
     a.g = g;
     a.xdb = xdb;
@@ -2887,7 +3167,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                            p.floor_db);
         OFP_LAUNCH_CHECK("k_rect_db");
     }
-    OFP_HIP(hipEventRecord(ev[2], stream));
+    if (timed) OFP_HIP(hipEventRecord(ev[2], stream));
 
     // --- followers
     {
@@ -2918,16 +3198,21 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             hipLaunchKernelGGL(k_ar_warm, dim3(grid), dim3(64), 0, stream, a, nt, used);
             OFP_LAUNCH_CHECK("k_ar_warm");
         }
-        int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
-                            d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &info[1], &info[3]);
-        if (rc != OFP_OK) return rc;
+        if (!hv_fm) {
+            pend.ar_nv = l.ar_chunks > 1 ? std::max(2, std::min(AHEAD_MAX_PASSES / 2, d->ar_pass_hint)) : 0;
+            if (int rc = run_jacobi_ahead("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, pass_flags, pend.ar_nv, stream))
+                return rc;
+        } else {
+            int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
+                                d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &pend.info[1], &pend.info[3]);
+            if (rc != OFP_OK) return rc;
+        }
     }
-    OFP_HIP(hipEventRecord(ev[3], stream));
+    if (timed) OFP_HIP(hipEventRecord(ev[3], stream));
     hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), tile_lds, stream, g,
                        dif, d_rel, p.floor_db, l.tu);
     OFP_LAUNCH_CHECK("k_rel_out");
-    OFP_HIP(hipEventRecord(ev[4], stream));
-    const float* rel = dif;
+    if (timed) OFP_HIP(hipEventRecord(ev[4], stream));
 
     // --- tracker (relative thresholds only; in manual mode its state is never read)
     float* thr_mn = reinterpret_cast<float*>(ws + l.o_thr_mn);
@@ -2962,19 +3247,26 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 hipLaunchKernelGGL(k_mm_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_mm_warm2");
         }
-        int rc = run_jacobi("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a, l.merge ? nt : 2 * 64 * cdiv(nt, 64),
-                            l.mm_chunks, used, ctr, d->h_flags,
-                            d->t.max_passes, d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &info[2], &info[3],
-                            +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch,
-                                hipStream_t st) {
-                                const int64_t n = m.n_chains * m.n_chunks;
-                                hipLaunchKernelGGL(k_mm_maxpass, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en,
-                                                   u, ch);
-                            },
-                            2 * nt);
-        if (rc != OFP_OK) return rc;
+        auto light = +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch, const int* gate,
+                         hipStream_t st) {
+            const int64_t n = m.n_chains * m.n_chunks;
+            hipLaunchKernelGGL(k_mm_maxpass, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
+        };
+        if (!hv_fm) {
+            pend.mm_nv = l.mm_chunks > 1 ? std::max(2, std::min(AHEAD_MAX_PASSES / 2, d->mm_pass_hint)) : 0;
+            if (int rc = run_jacobi_ahead("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a,
+                                          l.merge ? nt : 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, pass_flags + AHEAD_MAX_PASSES,
+                                          pend.mm_nv, stream, light, 2 * nt))
+                return rc;
+        } else {
+            int rc = run_jacobi("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a, l.merge ? nt : 2 * 64 * cdiv(nt, 64),
+                                l.mm_chunks, used, ctr, d->h_flags,
+                                d->t.max_passes, d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &pend.info[2], &pend.info[3],
+                                light, 2 * nt);
+            if (rc != OFP_OK) return rc;
+        }
     }
-    OFP_HIP(hipEventRecord(ev[5], stream));
+    if (timed) OFP_HIP(hipEventRecord(ev[5], stream));
 
     // --- crossings per block, then the hysteresis state machine
     ScanArgs sa;
@@ -2993,7 +3285,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sa.vflag = reinterpret_cast<uint32_t*>(ws + l.o_vflag);
     {
         const int64_t total = n_clips * l.nb * g.C;
-            const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
+        const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
         hipLaunchKernelGGL(k_block_scan, dim3(bs_grid), dim3(256), 0, stream, sa);
         OFP_LAUNCH_CHECK("k_block_scan");
     }
@@ -3005,12 +3297,12 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     va.pc = pc;
     va.nb = l.nb;
     va.C = g.C;
-    va.vis_j = reinterpret_cast<int32_t*>(ws + l.o_visj);
-    va.vfc = reinterpret_cast<int32_t*>(ws + l.o_vrec);
-    va.vlb = va.vfc + n_clips * l.nb * g.C;
-    va.vpc = va.vlb + n_clips * l.nb * g.C;
-    va.nv = reinterpret_cast<int32_t*>(ws + l.o_nv);
-    if (l.nb > 0) {
+    va.vis_j = const_cast<int32_t*>(sm.vis_j);
+    va.vfc = const_cast<int32_t*>(sm.vfc);
+    va.vlb = const_cast<int32_t*>(sm.vlb);
+    va.vpc = const_cast<int32_t*>(sm.vpc);
+    va.nv = va_nv;
+    {
         const int64_t n_lt = cdiv(l.nb, 256);
         int32_t* lt = reinterpret_cast<int32_t*>(ws + l.o_ltile);
         OFP_REQUIRE(n_lt * chains < (1ll << 31), "ofp_detect_offline: %lld block tiles in one call", (long long)(n_lt * chains));
@@ -3020,7 +3312,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_last_clear<true>, lgrid, dim3(64), 0, stream, (const int32_t*)sa.last_below, pc, lt, l.nb, g.C, n_lt);
         OFP_LAUNCH_CHECK("k_last_clear");
     }
-    if (l.nb > 0) {
+    {
         const int64_t n_tiles = cdiv(l.nb, 256);
         int32_t* vtile = reinterpret_cast<int32_t*>(ws + l.o_vtile);
         hipLaunchKernelGGL(k_visit_count, dim3((unsigned)n_tiles, (unsigned)n_clips), dim3(256), 0, stream, va, vtile, n_tiles);
@@ -3028,34 +3320,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_visit_scatter, dim3((unsigned)n_tiles, (unsigned)n_clips), dim3(256), 0, stream, va,
                            (const int32_t*)vtile, n_tiles);
         OFP_LAUNCH_CHECK("k_visit_count / k_visit_scan / k_visit_scatter");
-    } else {
-        OFP_HIP(hipMemsetAsync(va.nv, 0, n_clips * sizeof(int32_t), stream));
     }
-    SmArgs sm;
-    sm.g = g;
-    sm.nb = l.nb;
-    sm.n_clips = n_clips;
-    sm.cap = cap;
-    sm.cooldown = p.cooldown;
-    sm.vis_j = va.vis_j;
-    sm.vfc = va.vfc;
-    sm.vlb = va.vlb;
-    sm.vpc = va.vpc;
-    sm.nv = va.nv;
-    sm.records = d_records;
-    sm.counts = d_counts;
-    sm.clip_base = 0;
-    auto sequential_machine = [&]() -> int {
-        const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
-        size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)3 * tb * g.C * 4 + 64 * 4 + 16;
-        if (lds > 65536)
-            OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_state_machine),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
-        OFP_LAUNCH_CHECK("k_state_machine");
-        return OFP_OK;
-    };
-    int* sm_flag = nullptr;  // change counter of the last verification pass of the segmented machine
+    pend.sm_flag = false;
     if (l.sm_seg && l.nb > 0) {
         SmSegArgs ss;
         ss.n_seg = cdiv(l.nb, SM_SEG);
@@ -3075,63 +3341,37 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         hipLaunchKernelGGL(k_sm_offsets, dim3((unsigned)n_clips), dim3(64), 0, stream, sm, ss);
         hipLaunchKernelGGL(k_sm_seg, grid, dim3(64), lds, stream, sm, ss, -1, c);
         OFP_LAUNCH_CHECK("k_sm_seg / k_sm_offsets");
-        sm_flag = c + V - 1;
-        OFP_HIP(hipMemcpyAsync(d->h_flags + 40, sm_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+        pend.sm_flag = true;
+        OFP_HIP(hipMemcpyAsync(d->h_flags + 40, c + V - 1, sizeof(int), hipMemcpyDeviceToHost, stream));
     } else {
         if (int rc = sequential_machine()) return rc;
     }
-    auto backtrack = [&]() -> int {
-        if (!(p.backtrack && cap > 0)) return OFP_OK;
-        BtArgs bt;
-        bt.g = g;
-        bt.rel = rel;
-        bt.records = d_records;
-        bt.counts = d_counts;
-        bt.cap = cap;
-        bt.n_clips = n_clips;
-        bt.N = p.backtrack_buffer_size;
-        bt.alpha = p.backtrack_alpha;
-        bt.tol = p.backtrack_tol;
-        hipLaunchKernelGGL(k_backtrack, dim3((unsigned)cdiv(n_clips * cap, 64)), dim3(64), 0, stream, bt);
-        OFP_LAUNCH_CHECK("k_backtrack");
-        return OFP_OK;
-    };
     if (int rc = backtrack()) return rc;
-    OFP_HIP(hipEventRecord(ev[6], stream));
+    if (!hv_fm)
+        OFP_HIP(hipMemcpyAsync(d->h_flags + 96, pass_flags, 2 * AHEAD_MAX_PASSES * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (timed) OFP_HIP(hipEventRecord(ev[6], stream));
+    pend.valid = true;
+    if (enqueue_only) return OFP_OK;
     OFP_HIP(hipStreamSynchronize(stream));
-    if (sm_flag && (d->h_flags[40] != 0 || d->t.sm_segments == 2)) {  // (2: tests exercise this path)
-        // the last verification pass still changed a segment's start state (a machine that does not forget within
-        // four segments): the sequential machine decides
-        if (int rc = sequential_machine()) return rc;
-        if (int rc = backtrack()) return rc;
-        OFP_HIP(hipEventRecord(ev[6], stream));
-        OFP_HIP(hipStreamSynchronize(stream));
-        info[14] = 1;
-    }
-    // stage durations in nanoseconds (HIP events on the launch stream)
-    for (int k = 0; k < 6; ++k) {
-        float ms = 0.0f;
-        OFP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-        info[4 + k] = (int64_t)(ms * 1.0e6);
-    }
-    {
-        float ms = 0.0f;
-        OFP_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
-        info[10] = (int64_t)(ms * 1.0e6);
-    }
-    if (hp_cand_timed) {  // the single longest launch: k_hp_candidates
-        float ms = 0.0f;
-        OFP_HIP(hipEventElapsedTime(&ms, ev[8], ev[7]));
-        info[11] = (int64_t)(ms * 1.0e6);
-    }
-    if (h_info) std::memcpy(h_info, info, sizeof(info));
-    return OFP_OK;
+    return complete();
 }
 
 int ofp_detect_offline(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm, float* d_rel,
                        ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws, int64_t ws_bytes,
                        int64_t* h_info, void* stream) {
     return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info, stream, 0);
+}
+
+int ofp_detect_offline_enqueue(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm, float* d_rel,
+                               ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws, int64_t ws_bytes,
+                               void* stream) {
+    return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, nullptr, stream, 0, 1);
+}
+
+int ofp_detect_offline_complete(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm, float* d_rel,
+                                ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws, int64_t ws_bytes,
+                                int64_t* h_info, void* stream) {
+    return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info, stream, 7);
 }
 
 int ofp_detect_offline_begin(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
@@ -3144,6 +3384,12 @@ int ofp_detect_offline_finish(ofp_detector* d, const float* d_x, int64_t n_clips
                               float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws,
                               int64_t ws_bytes, int64_t* h_info, void* stream) {
     return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info, stream, 2);
+}
+
+int ofp_detect_offline_finish_enqueue(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
+                                      float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts, void* d_ws,
+                                      int64_t ws_bytes, void* stream) {
+    return detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, nullptr, stream, 2, 1);
 }
 
 int ofp_detect_offline_begin_input(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,

@@ -169,10 +169,7 @@ class BatchDetector:
         return (self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr()),
                 int(self.d.lib.ofp_detect_planar_stride(self.d.handle, n_clips, N, warm)))
 
-    def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
-        """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of
-        device tensors: ``records`` (uint8 view of ofp_onset [n_clips, cap]),
-        ``counts`` int64 [n_clips], ``rel`` float32 [n_clips, N', C] or None."""
+    def _call_args(self, x, warm, want_rel, cap_per_clip, out):
         if x.dim() == 2:
             x = x.unsqueeze(0)
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
@@ -189,28 +186,52 @@ class BatchDetector:
                 "counts": torch.zeros(n_clips, dtype=torch.int64, device=x.device),
                 "rel": torch.empty((n_clips, nb * B, C), dtype=torch.float32, device=x.device) if want_rel else None,
             }
-        info = (ctypes.c_int64 * 16)()
         rel = out["rel"]
-        if begun:  # the head was enqueued by begin(): run the remaining stages
-            check(self.d.lib.ofp_detect_offline_finish(
-                self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
-                out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
-                _stream_ptr(x.device)), "ofp_detect_offline_finish")
-        else:
-            check(self.d.lib.ofp_detect_offline(
-                self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
-                out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel(), info,
-                _stream_ptr(x.device)), "ofp_detect_offline")
+        out["cap"] = cap
+        return out, (self.d.handle, x.data_ptr(), n_clips, N, warm, rel.data_ptr() if rel is not None else None,
+                     out["records"].data_ptr(), cap, out["counts"].data_ptr(), ws.data_ptr(), ws.numel())
+
+    def _set_info(self, info):
         self.last_info = dict(
             hp_passes=info[0], ar_passes=info[1], mm_passes=info[2], repaired=info[3],
-            # stage durations, HIP events on the launch stream (milliseconds)
+            # stage durations, HIP events on the launch stream (milliseconds; zero for a call captured in a graph)
             stage_ms=dict(hp=info[4] / 1e6, db=info[5] / 1e6, ar=info[6] / 1e6, rel=info[7] / 1e6,
                           mm=info[8] / 1e6, logic=info[9] / 1e6, total=info[10] / 1e6,
                           hp_candidates=info[11] / 1e6),
             hp_candidate_steps=info[12],
             # staged candidates only (0 otherwise): distinct runs that walked a chunk
-            hp_chunk_runs=info[13])
-        out["cap"] = cap
+            hp_chunk_runs=info[13],
+            sequential_machine_decided=bool(info[14]),
+            # non-zero: the call was repeated with host-verified passes (include/onsetfp.h, info 15)
+            repeated_host_verified=int(info[15]))
+
+    def detect(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
+        """x: float32 CUDA tensor [n_clips, N, C] (or [N, C]).  Returns a dict of
+        device tensors: ``records`` (uint8 view of ofp_onset [n_clips, cap]),
+        ``counts`` int64 [n_clips], ``rel`` float32 [n_clips, N', C] or None.
+        One stream synchronisation, at the end of the call."""
+        out, args = self._call_args(x, warm, want_rel, cap_per_clip, out)
+        info = (ctypes.c_int64 * 16)()
+        name = "ofp_detect_offline_finish" if begun else "ofp_detect_offline"  # (begun: the head was enqueued by begin())
+        check(getattr(self.d.lib, name)(*args, info, _stream_ptr(x.device)), name)
+        self._set_info(info)
+        return out
+
+    def enqueue(self, x, warm=None, want_rel=True, cap_per_clip=None, out=None, begun=False):
+        """`detect` without its synchronisation: the whole call is only ENQUEUED on the current stream (which may be
+        capturing a hipGraph: allocate `out` and call `reserve` before the capture).  Synchronise (or replay the
+        graph and synchronise), then call ``complete`` with the same arguments."""
+        out, args = self._call_args(x, warm, want_rel, cap_per_clip, out)
+        name = "ofp_detect_offline_finish_enqueue" if begun else "ofp_detect_offline_enqueue"
+        check(getattr(self.d.lib, name)(*args, _stream_ptr(x.device)), name)
+        return out
+
+    def complete(self, x, out, warm=None):
+        """After the stream of ``enqueue`` (or a replay of the graph that captured it) has been synchronised."""
+        out, args = self._call_args(x, warm, out["rel"] is not None, out["cap"], out)
+        info = (ctypes.c_int64 * 16)()
+        check(self.d.lib.ofp_detect_offline_complete(*args, info, _stream_ptr(x.device)), "ofp_detect_offline_complete")
+        self._set_info(info)
         return out
 
     @staticmethod

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in header_functions():
         assert hasattr(L, name), f"{name} declared in onsetfp.h but not exported"
-    assert _lib.lib().ofp_abi_version() == 2
+    assert _lib.lib().ofp_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback():

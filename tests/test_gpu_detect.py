@@ -327,14 +327,52 @@ def test_g18_python_backtracking_on_the_gpu(det):
         assert np.array_equal(got, g[f"{name}_records"]), name
 
 
-def test_hundreds_of_iir_verification_rounds_stay_exact(det):
+@pytest.mark.parametrize("host_verify", [0, 1])
+def test_hundreds_of_iir_verification_rounds_stay_exact(det, host_verify):
     """One candidate per chunk, no warm-up, tiny chunks: every chunk of the IIR stage is a break and a chain
-    advances one chunk per round -- more rounds than the call has counter slots, so slots are recycled.
+    advances one chunk per round: hundreds of rounds inside the chain-local kernel, or (host_verify) more rounds
+    than the call has counter slots, so slots are recycled.
     (Found by the 1 500-case sweep of round 2: a recycled, re-zeroed slot was read as the previous round's
     "nothing left" flag and the stage stopped early.)"""
     x = synth.drum_hits(2, 6.5, SR, seed=77, period=0.31)
-    info, n = check_clip(det, x, tuning=dict(hp_chunk=1024, hp_warm=-1, hp_candidates=1), block_size=128, sr=SR)
+    info, n = check_clip(det, x, tuning=dict(hp_chunk=1024, hp_warm=-1, hp_candidates=1, host_verify=host_verify),
+                         block_size=128, sr=SR)
     assert info["hp_passes"] > 260 and n > 20
+
+
+@pytest.mark.parametrize("tuning", [None, dict(lane_merge=1, hp_dedupe=1, hp_early=1), dict(host_verify=-2)])
+def test_the_whole_call_is_one_hipgraph_and_replays_on_other_clips(det, tuning):
+    """ofp_detect_offline_enqueue issues no synchronisation and reads nothing back on the host, so ONE hipGraph
+    captures the complete call (reference loop: detection.py:73-82); replayed on the contents of a second and a
+    third clip in the same buffers it gives the oracle's records and relative envelope bit for bit."""
+    import torch
+    clips = [synth.c2_drums(6.0, 8, SR, seed=s) for s in (3, 4)] + [synth.drum_hits(8, 6.0, SR, seed=9, period=0.37)]
+    bd = det.BatchDetector(8, 256, sr=SR)
+    if tuning:
+        bd.set_tuning(**tuning)
+    x = torch.from_numpy(clips[0][None]).cuda().contiguous()
+    out = bd.detect(x, cap_per_clip=2048)   # buffers and work space exist before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        bd.enqueue(x, out=out, cap_per_clip=2048)
+    for src in (clips[1], clips[2], clips[0]):
+        x.copy_(torch.from_numpy(src[None]))
+        out["rel"].zero_()
+        out["counts"].zero_()
+        out["records"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        bd.complete(x, out)
+        if tuning and tuning.get("host_verify") == -2:   # the completion's fall-back, forced: the call again, host-verified
+            assert bd.last_info["repeated_host_verified"] == 1
+        else:
+            assert bd.last_info["stage_ms"]["total"] == 0 and bd.last_info["repeated_host_verified"] == 0
+        recs = det.BatchDetector.records_to_numpy(out)[0]
+        c, o, orel = oracle_records(src, block_size=256, sr=SR)
+        assert np.array_equal(recs["channel"], c) and np.array_equal(recs["sample"], o)
+        assert np.array_equal(bits(out["rel"][0].cpu().numpy()), bits(orel))
+        assert len(c) > 50
 
 
 THROUGHPUT = dict(lane_merge=1, hp_dedupe=1, hp_early=1, sm_segments=1)
