@@ -186,23 +186,68 @@ def synth_batch(kind, idents, seconds, C, workers):
     if workers <= 1 or len(jobs) == 1:
         return [_synth_worker(j) for j in jobs]
     import multiprocessing as mp
-    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+    pool = mp.get_context("spawn").Pool(min(workers, len(jobs)))
+    try:
         return pool.map(_synth_worker, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+    finally:  # close + join: the workers leave by themselves (terminate() signals them while a profiler's preloaded
+        pool.close()  # library is finalising in them, which fills its log with "Aborted")
+        pool.join()
+
+
+def _spin_worker(n):
+    """A fixed amount of single-threaded work (numpy-free: nothing here can fan out by itself); -> its own seconds."""
+    t0 = time.perf_counter()
+    acc = 0
+    for i in range(n):
+        acc = (acc * 1103515245 + 12345 + i) & 0x7fffffff
+    return time.perf_counter() - t0
+
+
+def calibrated_cores(limit):
+    """How many processes this job can really run side by side: the same spin loop in k = 1, 2, 4 ... processes until
+    the slowest of them takes 20 % longer than one alone (an affinity mask or cpu_count() says what the box has, not
+    what this job is given).  -> (cores, {k: seconds of the slowest})"""
+    import multiprocessing as mp
+    n_iter = 3_000_000
+    curve, cores, base = {}, 1, None
+    k = 1
+    while k <= limit:
+        pool = mp.get_context("spawn").Pool(k)
+        try:
+            pool.map(_spin_worker, [1000] * k)             # (processes up and imported)
+            worst = max(pool.map(_spin_worker, [n_iter] * k, chunksize=1))
+        finally:
+            pool.close()
+            pool.join()
+        curve[k] = round(worst, 3)
+        if base is None:
+            base = worst
+        if worst > 1.2 * base:
+            break
+        cores = k
+        k *= 2
+    return cores, curve
 
 
 def cpu_fanout(kind, seconds, sd):
-    """One process per usable core, one clip each (the process-per-core fan-out over clips)."""
+    """One process per core this job really has (calibrated_cores), one clip each (the process-per-core
+    fan-out over clips)."""
     import multiprocessing as mp
-    n = usable_cpus()
+    n, curve = calibrated_cores(usable_cpus())
     jobs = [(kind, 1000 + i, seconds, sd) for i in range(n)]
     t0 = time.perf_counter()
-    with mp.get_context("spawn").Pool(n) as pool:
-        res = pool.map(_fanout_worker, jobs)
+    pool = mp.get_context("spawn").Pool(n)
+    try:
+        res = pool.map(_fanout_worker, jobs, chunksize=1)
+    finally:
+        pool.close()
+        pool.join()
     wall = time.perf_counter() - t0
     busy = max(s for _, s in res)  # the clips run side by side: the slowest one bounds the compute time
-    return dict(value=sum(f for f, _ in res) / busy, cores=n, wall_s=round(wall, 2),
-                sample=f"{n} processes x one {seconds:.0f} s clip each through oracle/, {busy:.2f} s for the slowest "
-                       "(process start-up and clip synthesis excluded)")
+    return dict(value=sum(f for f, _ in res) / busy, cores=n, wall_s=round(wall, 2), spin_seconds_by_processes=curve,
+                sample=f"{n} processes (the count at which a spin loop still runs within 20 % of its lone speed; the mask "
+                       f"allows {usable_cpus()}) x one {seconds:.0f} s clip each through oracle/, {busy:.2f} s for the "
+                       "slowest (process start-up and clip synthesis excluded)")
 
 
 def main():
@@ -212,11 +257,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c2", "c4"], default=None)
     ap.add_argument("--clips", type=int, default=16, help="c2: distinct clips per GPU and step")
-    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 3 for c2; 3 / 4 / 8 for c4 shards of > 128 / <= 128 / <= 64 clips)")
+    ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 6 for c2; 6 / 12 for c4 shards of > 128 / <= 128 clips; with two or more in flight the detector runs with its throughput settings lane_merge and hp_dedupe unless --tuning says otherwise)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra figures (one clip per step, whole batch)")
     ap.add_argument("--tuning", type=str, default="", help="JSON dict of ofp_detect_tuning fields (experiments)")
+    ap.add_argument("--exp", type=str, default="", help="EXPERIMENTS (the line says so in config.experiment and is not the "
+                    "metric): JSON dict with detector kwargs (hipass_freq, on_threshold, ...) and/or \"no_stft\": true")
     ap.add_argument("--rehearsal", action="store_true", help="control flow only, no GPU work (CPU tests)")
     ap.add_argument("--shard-of", type=int, default=0, help="c4 on ONE GPU: process only rank 0's shard of a world of this "
                     "size (what one rank of an N-GPU run does per step, without the exchange partners); the line is "
@@ -346,7 +393,13 @@ def main():
         else:
             slot0 = make_clips(0)
             slots = [slot0] + [derive(slot0, s) for s in range(1, D)]
-        pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip) for _ in range(D)]
+        exp = json.loads(args.exp) if args.exp else {}
+        no_stft = bool(exp.pop("no_stft", False))
+        pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip, **exp) for _ in range(D)]
+        for pp in pipes:
+            pp.skip_spectral = no_stft
+        if args.exp:
+            result_extra["experiment"] = args.exp
         if tuning:
             for pp in pipes:
                 pp.detector.set_tuning(**tuning)
@@ -426,6 +479,28 @@ def main():
     # ---- untimed extras on the same process: what one clip per step costs (c2) / the whole batch on one GPU (c4)
     extras = {}
     alone_ms = {}
+    copy_gbs = None
+    host_clip0 = None
+    if not rehearsal:
+        host_clip0 = slots[(args.steps - 1) % D][1]  # host copy of clip 0 of the batch the last timed step ran on (c4: slot 0 only)
+        if rank == 0:
+            # (a) what a plain device-to-device copy reaches on THIS GPU (2 GiB in, 2 GiB out: far beyond the caches):
+            # the practical ceiling next to the 8 TB/s specification
+            try:
+                ca = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+                cb = torch.empty_like(ca)
+                cb.copy_(ca)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(dev)
+                e0.record()
+                for _ in range(5):
+                    cb.copy_(ca)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                copy_gbs = 5 * 2 * ca.numel() * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9
+                del ca, cb
+            except Exception:
+                copy_gbs = None
     if D > 1 and not rehearsal:
         # the SAME batch step with nothing else on the GPU (two repetitions after the timed region): what each launch
         # takes when it does not share the chip with the other steps in flight -- next to the in-flight durations
@@ -457,6 +532,86 @@ def main():
                                            "note": "the same path on ONE 8-channel clip per step (8 chains), steps one "
                                                    "after the other, this rank only"}
             del p1
+        if world == 1 and D > 1:
+            # (b) the same steps with the batch uploaded from pinned host memory before every step (the uploads of the
+            # steps in flight share the PCIe link and overlap the other steps' compute): never `value`
+            try:
+                n_up = max(D, min(args.steps, 2 * D))
+                pinned = slots[0][0].cpu().pin_memory()
+                copy_streams = [torch.cuda.Stream(dev) for _ in range(D)]
+
+                def step_with_upload(w):
+                    torch.cuda.set_device(local)
+                    with torch.cuda.stream(copy_streams[w]):
+                        slots[w][0].copy_(pinned, non_blocking=True)
+                    streams[w].wait_stream(copy_streams[w])
+                    return run_step(w, False)
+
+                for f in [workers[i % D].submit(step_with_upload, i % D) for i in range(D)]:
+                    f.result()
+                barrier()
+                tu = time.perf_counter()
+                for f in [workers[i % D].submit(step_with_upload, i % D) for i in range(n_up)]:
+                    f.result()
+                barrier()
+                ms_up = (time.perf_counter() - tu) / n_up * 1e3
+                t_c = time.perf_counter()
+                for _ in range(3):
+                    slots[0][0].copy_(pinned, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                h2d_gbs = 3 * pinned.numel() * 4 / (time.perf_counter() - t_c) / 1e9
+                extras["including_h2d"] = {"frames_per_s": round(frames_total / (ms_up / 1e3)), "ms_per_step": round(ms_up, 3),
+                                           "h2d_GBps_alone": round(h2d_gbs, 1), "batch_MB": round(pinned.numel() * 4 / 1e6),
+                                           "note": "the same steps in flight, each preceded by the upload of its batch from "
+                                                   "pinned host memory (PCIe-bound: not the metric's value)"}
+                del pinned
+            except Exception as e:  # (an extra figure must not cost the line)
+                extras["including_h2d"] = {"error": repr(e)[:200]}
+        if world == 1 and workload == "c2":
+            # (d) BASELINE configs[3] on this one GPU, same settings: the base a 1 -> N curve of the C4 workload needs in
+            # the N = 1 record (the N > 1 lines run C4 sharded; `whole_batch_on_one_gpu` there is the same measurement)
+            try:
+                del pipes[:]
+                slots.clear()
+                torch.cuda.empty_cache()
+                Dc, Cc, Nc = 6, C4["C"], int(C4["seconds"] * SR)
+                xs4 = synth_batch("c4", list(range(C4["clips"])), C4["seconds"], Cc, max(1, usable_cpus()))
+                x4 = torch.from_numpy(np.stack(xs4)).to(dev).contiguous()
+                del xs4
+                xs_slots = [x4] + [(torch.roll(x4, s, dims=2) * (1.0 - 0.07 * s)).contiguous() for s in range(1, Dc)]
+                p4 = [FingerprintPipeline(Cc, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=1024) for _ in range(Dc)]
+                for pp in p4:
+                    pp.detector.set_tuning(**(tuning or dict(lane_merge=1, hp_dedupe=1)))
+                s4 = [torch.cuda.Stream(dev) for _ in range(Dc)]
+
+                def c4_step(w):
+                    torch.cuda.set_device(local)
+                    with torch.cuda.stream(s4[w]):
+                        o4 = p4[w].run(xs_slots[w])
+                        pack_clips(o4["records"], o4["counts"], C4["clips"] * 256)
+                    s4[w].synchronize()
+
+                from concurrent.futures import ThreadPoolExecutor as _TPE4
+                pool4 = [_TPE4(1) for _ in range(Dc)]
+                for f in [pool4[i % Dc].submit(c4_step, i % Dc) for i in range(Dc)]:
+                    f.result()
+                n4 = 2 * Dc
+                torch.cuda.synchronize(dev)
+                t4 = time.perf_counter()
+                for f in [pool4[i % Dc].submit(c4_step, i % Dc) for i in range(n4)]:
+                    f.result()
+                torch.cuda.synchronize(dev)
+                ms4 = (time.perf_counter() - t4) / n4 * 1e3
+                fr4 = C4["clips"] * Cc * synth.n_frames(Nc, NFFT, HOP)
+                extras["c4_on_one_gpu"] = {"ms_per_step": round(ms4, 3), "frames_per_s": round(fr4 / (ms4 / 1e3)),
+                                           "frames_per_step": fr4, "steps_in_flight": Dc, "steps": n4,
+                                           "note": "BASELINE configs[3] (512 clips x 4 ch x 10 s) on this one GPU with the bench's "
+                                                   "detector settings: the N = 1 point of the C4 strong-scaling curve"}
+                for e4 in pool4:
+                    e4.shutdown()
+                del p4, xs_slots, x4
+            except Exception as e:
+                extras["c4_on_one_gpu"] = {"error": repr(e)[:200]}
         if workload == "c4" and world > 1 and rank == 0:
             # the base of the strong-scaling ratio: all 512 clips on ONE GPU with the same settings, steps in flight
             # as the single-GPU bench runs them (four deep here; rank 0's shard tiled to 512 clips: the same shapes
@@ -547,14 +702,18 @@ def main():
                             "onsets_gathered": int(len(recs)), "ranks_in_exchange": ranks_seen, "backend": backend if world > 1 else "-",
                             "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D, "detector_tuning": tuning or "library defaults",
                             "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
-                            "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3)}, **extras),
+                            "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3)}, **extras, **result_extra),
             "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": 1, "avg_launch_ms": dom_ms, "algorithmic_bytes_per_frame": dom_bytes,
+                         "peak_measured": ({"device_copy_GBps": round(copy_gbs, 1), "frac_of_it": achieved / copy_gbs,
+                                            "note": "read + write rate of a 2 GiB device-to-device copy on this GPU in this run"}
+                                           if copy_gbs else None),
                          "note": "per launch: algorithmic bytes of the launch / its duration (HIP events on its stream) "
                                  "while the other steps in flight share the GPU with it"},
             "roofline_e2e": {"bound": "hbm", "achieved": e2e_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                              "frac": e2e_gbs / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_frame": BYTES_E2E,
+                             "frac_of_measured_copy": (e2e_gbs / (copy_gbs * world) if copy_gbs else None),
                              "note": "whole step: 4 292 B per frame (samples in, rel + |X|^2 + mel + logits out) x frames / ms_per_step"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "detector_passes": {k: passes[k] for k in ("hp_passes", "ar_passes", "mm_passes", "repaired")},
@@ -586,11 +745,11 @@ def main():
             n = int(secs * SR)
             sd = fcnn_state()
             last = (args.steps - 1) % D
-            if slots[last][1] is None:  # c4 with steps in flight: only slot 0 has a host copy
+            if host_clip0 is None:  # c4 with steps in flight: only slot 0 has a host copy
                 last = 0
                 out, _ = finish(*run_step(0, False), False)
                 recs = records_to_numpy(unpack_gathered(_))
-            x0 = np.ascontiguousarray(slots[last][1][:n])   # clip 0 of the batch the checked step ran on
+            x0 = np.ascontiguousarray((host_clip0 if host_clip0 is not None else slots[last][1])[:n])   # clip 0 of the batch the checked step ran on
             cb = oracle_pass(x0, sd)
             r0 = recs[recs["clip"] == 0]
             k = r0["sample"] < (n // HOP) * HOP

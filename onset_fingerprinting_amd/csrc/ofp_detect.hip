@@ -2819,9 +2819,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     auto sequential_machine = [&]() -> int {
         const int tb = std::max(1, std::min(64, (64 * SM_NPL) / g.C));
         size_t lds = (size_t)g.C * (8 + 4 + 1 + 1) + (size_t)3 * tb * g.C * 4 + 64 * 4 + 16;
-        if (lds > 65536)
-            OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_state_machine),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static ofp::LdsAttrCache attr;
+        if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_state_machine), lds, attr)) return rc;
         hipLaunchKernelGGL(k_state_machine, dim3((unsigned)n_clips), dim3(64), lds, stream, sm);
         OFP_LAUNCH_CHECK("k_state_machine");
         return OFP_OK;

@@ -353,9 +353,13 @@ __global__ __launch_bounds__(FusedCfg<F>::WGS) void k_hop_fused(HopArgs a, ofpst
     } else {  // the onset-strength workgroup (only launched when enabled)
         hop_strength_body<F, FusedCfg<F>::WGS>(a, done + 1, smem);
     }
+    // EVERY thread drains its own stores to the result block (pinned host memory) and the ring before the barrier:
+    // the barrier does not wait for outstanding stores, and a fence by thread 0 alone covers only its own wave, so
+    // the completion word could otherwise become visible while another wave's `rel` / `mel` rows are still in flight
+    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();  // this workgroup's results (host memory) before its ticket
+        __threadfence_system();  // (orders the ticket after the barrier's view of the other waves' fences)
         const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(a.ctl + 1), 1ull);
         if (t == gridDim.x - 1) {  // every workgroup has read ctl[0] and published its results
             a.ctl[1] = 0;
@@ -402,6 +406,7 @@ struct ofp_hop_session {
     size_t lds = 0;
     int64_t pushed = 0;   // hops submitted
     bool in_flight = false;
+    bool retired = true;   // the last hop's kernel is known to have left the stream (a polled completion is not that)
 };
 
 namespace {
@@ -570,6 +575,9 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
                 cfg->fb_nnz, cfg->n_fft / 2 + 1);
     OFP_REQUIRE(cfg->n_mels <= 127 && cfg->fb_nnz / MEL_SEG + cfg->n_mels <= MEL_MAXSEG,
                 "ofp_hop_create: at most 127 bands and %d 32-tap segments", MEL_MAXSEG);
+    OFP_REQUIRE(!cfg->strength || (cfg->strength_ring >= 1 && cfg->max_length >= 1 && cfg->avg_length >= 1 &&
+                                   cfg->max_length <= cfg->strength_ring && cfg->avg_length <= cfg->strength_ring),
+                "ofp_hop_create: onset strength needs 1 <= max_length, avg_length <= strength_ring");
     OFP_REQUIRE(!cfg->mlp || cfg->mlp->plan.dims[0] == cfg->n_mels,
                 "ofp_hop_create: the classifier takes %d inputs, the filterbank has %d bands",
                 cfg->mlp ? cfg->mlp->plan.dims[0] : 0, cfg->n_mels);
@@ -662,9 +670,6 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     a.count = reinterpret_cast<int64_t*>(s->d_res + s->o_count);
     a.hop_index = reinterpret_cast<int64_t*>(s->d_res + s->o_index);
     if (cfg->strength) {
-        OFP_REQUIRE(cfg->strength_ring >= 1 && cfg->max_length >= 1 && cfg->avg_length >= 1 &&
-                        cfg->max_length <= cfg->strength_ring && cfg->avg_length <= cfg->strength_ring,
-                    "ofp_hop_create: onset strength needs 1 <= max_length, avg_length <= strength_ring");
         const int bins = s->n_fft / 2 + 1;
         s->sg_floats = (size_t)bins + 4 + (size_t)cfg->strength_ring;
         HOP_TRY(hipMalloc(&s->d_sg, s->sg_floats * 4));
@@ -686,7 +691,10 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
         s->sg_init[1] = cfg->oe_min0;
         s->sg_init[2] = cfg->oe_max0;
         s->lds_strength = (size_t)(3 * M + M / 16 + 2) * 8 + (size_t)B * C * 4 + 64 * 4;
-        OFP_REQUIRE(s->lds_strength <= 160 * 1024, "ofp_hop_create: the hop (%d x %d samples) does not fit the LDS", B, C);
+        if (s->lds_strength > 160 * 1024) {
+            ofp_hop_destroy(s);
+            return ofp::fail(OFP_ERR_INVALID, "ofp_hop_create: the hop (%d x %d samples) does not fit the LDS", B, C);
+        }
     }
     // Fused form (one launch per hop, hop and result block in pinned host memory) whenever the detector
     // fits one workgroup of the fused kernel; OFP_HOP_GRAPH=nodes keeps the five-node graph.
@@ -757,6 +765,7 @@ int ofp_hop_warmup(ofp_hop_session* s, const float* h_x, int64_t n_rows) {
                                                   s->stream)
                              : ofp::fail(OFP_ERR_HIP, "ofp_hop_warmup: %s", hipGetErrorString(e));
     (void)hipStreamSynchronize(s->stream);
+    s->retired = true;
     (void)hipFree(d);
     return rc;
 }
@@ -782,8 +791,10 @@ int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records,
         for (int spin = 0; spin < 2000000 && *flag != s->pushed; ++spin) __builtin_ia32_pause();
         if (*flag != s->pushed) OFP_HIP(hipStreamSynchronize(s->stream));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        s->retired = false;  // the kernel has published its results; it may not have retired from the stream yet
     } else {
         OFP_HIP(hipStreamSynchronize(s->stream));
+        s->retired = true;
     }
     s->in_flight = false;
     const unsigned char* r = s->h_res;
@@ -816,6 +827,11 @@ int ofp_hop_push(ofp_hop_session* s, const float* h_hop, int64_t* n_onsets, ofp_
 int ofp_hop_ring_read(ofp_hop_session* s, int64_t n_rows, float* h_out) {
     OFP_REQUIRE(s && h_out && n_rows >= 0 && n_rows <= s->R, "ofp_hop_ring_read: bad argument");
     OFP_REQUIRE(!s->in_flight, "ofp_hop_ring_read: a hop is in flight (collect it first)");
+    // the copies below are not stream-ordered: the last hop's kernel (polled, not synchronised) must have retired
+    if (!s->retired) {
+        OFP_HIP(hipStreamSynchronize(s->stream));
+        s->retired = true;
+    }
     // audio[-n_rows:] of the reference's CircularArray: the rows ending at the write cursor, oldest first
     const int64_t end = s->pushed * s->B;
     const size_t row = (size_t)s->C * 4;

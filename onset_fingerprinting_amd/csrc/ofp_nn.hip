@@ -329,12 +329,8 @@ int ofp_mlp_forward(const ofp_mlp* m, const float* d_x, int64_t n, float* d_y, v
     const size_t lds = (size_t)ofp_mlp_lds_bytes(m);
     OFP_REQUIRE(lds <= 160 * 1024, "ofp_mlp_forward: the network (%d parameters) does not fit the LDS; run it layer by "
                 "layer with ofp_dense", m->plan.n_params);
-    static size_t attr_set = 0;
-    if (lds > 65536 && lds > attr_set) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set = lds;
-    }
+    static ofp::LdsAttrCache attr;
+    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp), lds, attr)) return rc;
     const int64_t row_tiles = cdiv(n, 16);
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv(row_tiles, MLP_WAVES), 256 * 8);
     hipLaunchKernelGGL(k_mlp, dim3(grid), dim3(64 * MLP_WAVES), lds, (hipStream_t)stream, m->plan, d_x, n, d_y);

@@ -199,12 +199,8 @@ int ofp_resample_windows(const float* d_audio, int64_t n_samples, int32_t n_chan
                 "ofp_resample_windows: windows of up to 2048 samples (num = %d, longest input %d)", num, max_nx);
     ResampleArgs a{d_audio, n_samples, n_channels, d_start, d_nx, num, max_nx, d_out};
     const size_t lds = (size_t)(max_nx + num + std::min(num, max_nx) / 2 + 1) * 16 + (size_t)max_nx * 4 + 16;
-    static size_t attr_set = 0;
-    if (lds > 65536 && lds > attr_set) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resample), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_set = lds;
-    }
+    static ofp::LdsAttrCache attr;
+    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_resample), lds, attr)) return rc;
     hipLaunchKernelGGL(k_resample, dim3((unsigned)(n_items * n_channels)), dim3(256), lds, (hipStream_t)stream, a);
     OFP_LAUNCH_CHECK("k_resample");
     return OFP_OK;

@@ -414,12 +414,8 @@ int launch_power_s(const float* x, int64_t n_samples, int C, int hop, int64_t H,
         OFP_REQUIRE(lds <= 160 * 1024, "classifier epilogue: %zu bytes of LDS needed, 160 KiB available", lds);
     }
     if (getenv("OFP_DEBUG_LDS")) fprintf(stderr, "k_stft_power<%d,%d>: %zu bytes of LDS per workgroup\n", F, (int)MLP, lds);
-    static size_t attr_set = 0;
-    if (lds > 65536 && lds > attr_set) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_power<F, MLP, SLIDE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
+    static ofp::LdsAttrCache attr;  // (one per instantiation)
+    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_stft_power<F, MLP, SLIDE>), lds, attr)) return rc;
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
     hipLaunchKernelGGL((k_stft_power<F, MLP, SLIDE>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
@@ -450,12 +446,8 @@ int launch_power(const float* x, int64_t n_samples, int C, int hop, int64_t H, i
 template <int F>
 int launch_frames(const FrameArgs& a, hipStream_t stream) {
     using G = Cfg<F>;
-    static bool attr_set = false;
-    if (!attr_set && G::lds_bytes > 65536) {
-        OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_frames<F>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes));
-        attr_set = true;
-    }
+    static ofp::LdsAttrCache attr;
+    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_stft_frames<F>), G::lds_bytes, attr)) return rc;
     int64_t groups = cdiv(a.n_frames, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
     hipLaunchKernelGGL(k_stft_frames<F>, dim3(grid), dim3(G::WG), G::lds_bytes, stream, a);

@@ -298,12 +298,8 @@ int ofp_stream_process(ofp_detector* d, void* d_state, const float* d_x, int64_t
         // enough lanes for the elementwise phases of a hop, at least two per channel for the role lanes
         const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(ofp::align_up(2 * C, 64),
                                                     std::min<int64_t>(256, ofp::align_up((int64_t)d->p.block_size * C, 64))));
-        static size_t attr_set = 0;
-        if (par_lds > 65536 - 16384 && par_lds > attr_set) {
-            OFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream_par),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
-            attr_set = par_lds;
-        }
+        static ofp::LdsAttrCache attr;
+        if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_stream_par), par_lds, attr, 65536 - 16384)) return rc;
         hipLaunchKernelGGL(k_stream_par, dim3(1), dim3(threads), par_lds, (hipStream_t)stream, a);
         OFP_LAUNCH_CHECK("k_stream_par");
         return OFP_OK;

@@ -465,9 +465,14 @@ def filter_data(x: np.ndarray, direction: str, device=0) -> np.ndarray:
     axis 0 is negative ("up") / positive ("down"); returns x."""
     if direction not in ("up", "down"):
         raise RuntimeError(f"Unknown onset direction {direction=}!")
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float32):
+        # the reference keeps the caller's dtype and takes the difference in it; a float64 array rounded to float32 can
+        # lose the sign of a difference, so anything but float32 is refused rather than answered approximately
+        raise TypeError(f"filter_data: float32 array expected (the device kernel computes in float32), got "
+                        f"{getattr(x, 'dtype', type(x))}")
     dev = _dev(device)
     _lib.require_gpu(dev.index or 0)
-    a = np.ascontiguousarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(x)
     n = a.shape[0] if a.ndim else 0
     cols = int(a.size // max(n, 1)) if n else 1
     xd = torch.from_numpy(a.reshape(n, cols)).to(dev)

@@ -99,6 +99,13 @@ class FingerprintPipeline:
         self.detector.begin_input(x)
         self._head.record(main)
         self.detector.begin_iir(x)
+        if getattr(self, "skip_spectral", False):  # (measurement only: what the detector costs without the spectral branch)
+            det = self.detector.detect(x, out=b["det"], cap_per_clip=b["det"]["records"].shape[1], begun=True)
+            out = dict(records=det["records"], counts=det["counts"], cap=det["cap"], rel=det["rel"], power=None, mel=None,
+                       logits=None, info=self.detector.last_info)
+            if timed:
+                out["spectral_ms"] = dict(stft_mel=0.0, mlp=0.0)
+            return out
         # the spectral branch needs the planar copy only: it starts beside the candidate launch
         side.wait_event(self._head)
         with torch.cuda.stream(side):

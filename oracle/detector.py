@@ -10,6 +10,10 @@ _SO = _HERE / "libofp_oracle.so"
 
 
 def _load():
+    import os
+    so = os.environ.get("OFP_ORACLE_SO")  # the CPU sanitizer test substitutes its ASan / UBSan build (oracle/Makefile)
+    if so:
+        return ctypes.CDLL(so)
     if not _SO.exists():
         subprocess.check_call(["make", "-C", str(_HERE), str(_SO)])
     return ctypes.CDLL(str(_SO))

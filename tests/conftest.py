@@ -13,6 +13,7 @@ GOLDEN = REPO / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a BASELINE configuration at its full stated size (minutes of host-side synthesis and oracle time; part of -m gpu, deselect with -m 'gpu and not slow')")
 
 
 def load_golden(name):

@@ -266,3 +266,106 @@ def test_collation_block_kernel_equals_the_tensor_form():
         if total <= cap_total and n_clips != 64:
             assert torch.equal(unpack_gathered(all_gather_blocks(got)), flatten_records(r8, counts, cap) if off == 0 else
                                unpack_gathered(all_gather_blocks(want)))
+
+
+def test_two_ranks_on_one_gpu_gather_what_one_process_computes(mods, tmp_path):
+    """The N > 1 path end to end with real device buffers: two FRESH child processes (gloo, both on cuda:0, started
+    before they touch the GPU) each run the detector on their shard of 16 C4 clips, build the collation block on the
+    device (ofp_pack_records) and exchange it; what rank 0 gathers equals the records of ONE process over all 16
+    clips, and the oracle's for two of them (bench.py's N > 1 step without the timing)."""
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    detection, _ = mods
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "gathered.npy"
+    child = str(Path(__file__).with_name("_two_ranks_child.py"))
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(port), str(out)]) for r in range(2)]
+    try:
+        codes = [pr.wait(timeout=300) for pr in procs]
+    finally:
+        for pr in procs:  # exactly the children started above
+            if pr.poll() is None:
+                pr.kill()
+    assert codes == [0, 0]
+    got = np.load(out)
+    xs = np.stack([synth.c4_clip(i, 3.0, 4, SR) for i in range(16)])
+    one = detection.BatchDetector.records_to_numpy(detection.BatchDetector(4, 256, sr=SR).detect(torch.from_numpy(xs).cuda()))
+    want = np.concatenate(one)
+    assert len(got) == len(want) > 100
+    for f in ("clip", "channel", "sample"):
+        assert np.array_equal(got[f], want[f]), f
+    for i in (3, 12):  # one clip of each rank's shard against the oracle
+        ch, on, _ = oracle.detect_onsets_amplitude(xs[i], block_size=256, sr=SR)
+        mine = got[got["clip"] == i]
+        assert np.array_equal(mine["channel"], np.array(ch)) and np.array_equal(mine["sample"], np.array(on))
+
+
+@pytest.mark.slow
+def test_c4_at_its_stated_size_512_clips_on_one_gpu(mods):
+    """BASELINE configs[3] at full size on one GPU: 512 clips x 4 ch x 10 s in ONE call (2 048 chains) in the bench's
+    throughput settings == the same clips one call each in the default settings (every 8th clip), and 16 sampled
+    clips == the oracle (indices exact, `rel` bit for bit)."""
+    detection, _ = mods
+    import bench
+    xs = np.stack(bench.synth_batch("c4", list(range(512)), 10.0, 4, 16))
+    xd = torch.from_numpy(xs).cuda().contiguous()
+    bd = detection.BatchDetector(4, 256, sr=SR)
+    bd.set_tuning(lane_merge=1, hp_dedupe=1)
+    out = bd.detect(xd, cap_per_clip=1024)
+    assert not bd.last_info["repeated_host_verified"]
+    recs = detection.BatchDetector.records_to_numpy(out)
+    single = detection.BatchDetector(4, 256, sr=SR)
+    for i in range(0, 512, 8):
+        o1 = single.detect(xd[i:i + 1], cap_per_clip=1024)
+        r1 = detection.BatchDetector.records_to_numpy(o1)[0]
+        assert np.array_equal(r1["sample"], recs[i]["sample"]) and np.array_equal(r1["channel"], recs[i]["channel"]), i
+        assert torch.equal(o1["rel"][0], out["rel"][i]), i
+    total = 0
+    for i in range(5, 512, 32):
+        ch, on, orel = oracle.detect_onsets_amplitude(xs[i], block_size=256, sr=SR)
+        assert np.array_equal(recs[i]["channel"], np.array(ch)) and np.array_equal(recs[i]["sample"], np.array(on)), i
+        assert (recs[i]["clip"] == i).all()
+        assert np.array_equal(bits(out["rel"][i].cpu().numpy()), bits(orel)), i
+        total += len(ch)
+    assert total > 1500
+
+
+@pytest.mark.slow
+def test_c3_at_its_stated_size_64_channels_600_s(mods):
+    """BASELINE configs[2] at full size: ONE clip of 64 ch x 600 s @ 48 kHz (1.84 G samples), 2048/512, 40 mel + FCNN with
+    |X|^2 kept on the chip (want_power=False): onset indices and the relative envelope equal the oracle's over the
+    WHOLE clip (exact; the oracle needs most of a minute), mel / logits on two channels within 1e-4."""
+    detection, pipeline = mods
+    C, F, H = 64, 2048, 512
+    x = synth.c3_stream(600.0, C, SR, seed=2)
+    pipe = pipeline.FingerprintPipeline(C, F, H, SR, 40, device=0, want_power=False)
+    out = pipe.run(torch.from_numpy(x).cuda().unsqueeze(0).contiguous())
+    torch.cuda.synchronize()
+    assert out["power"] is None and not out["info"]["repeated_host_verified"]
+    n = int(out["counts"][0])
+    assert 0 < n <= out["cap"]
+    rec = out["records"][0, :n].cpu().numpy().view(np.dtype([("clip", np.int32), ("channel", np.int32),
+                                                            ("sample", np.int64)])).reshape(-1)
+    ch, on, rel = oracle.detect_onsets_amplitude(x, block_size=H, sr=SR)
+    assert len(ch) > 20000
+    assert np.array_equal(rec["channel"], np.array(ch)) and np.array_equal(rec["sample"], np.array(on))
+    g_rel = out["rel"][0].cpu().numpy()
+    assert np.array_equal(g_rel.view(np.uint32), rel.view(np.uint32))
+    del rel, g_rel
+    sd = {k: v.numpy() for k, v in pipe.classifier.state_dict().items()}
+    fb = oracle.mel_filterbank(SR, F, 40).astype(np.float64)
+    Hn = 2000
+    ns = F + (Hn - 1) * H
+    for c in (0, C - 1):
+        P = oracle.dense_power_frames(np.ascontiguousarray(x[:ns, c:c + 1]), F, H)[0]
+        mel = P @ fb.T
+        big = mel >= 1e-5 * mel.max()
+        gm = out["mel"][0, c, :Hn].cpu().numpy()
+        assert (np.abs(gm - mel)[big] / mel[big]).max() < 1e-4 and np.abs(gm - mel).max() / mel.max() < 1e-4
+        lg = oracle.fcnn_forward(sd, mel)
+        assert np.abs(out["logits"][0, c, :Hn].cpu().numpy() - lg).max() / np.abs(lg).max() < 1e-4

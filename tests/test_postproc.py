@@ -76,6 +76,11 @@ def test_gpu_postproc_matches_reference():
     assert np.array_equal(detection.filter_data(g["fil_x"][:, 0].copy(), "up"), g["fil_1d_up"])
     with pytest.raises(RuntimeError):
         detection.filter_data(g["fil_x"].copy(), "sideways")
+    with pytest.raises(TypeError):  # float32 only: a float64 array is not rounded behind the caller's back
+        detection.filter_data(g["fil_x"].astype(np.float64), "up")
+    xs = g["fil_x"].copy()[::2]     # a strided view is filtered in place as well
+    want = oracle.filter_data(np.ascontiguousarray(xs), "down")
+    assert detection.filter_data(xs, "down") is xs and np.array_equal(xs, want)
     a = _reg_audio(g)
     for name, kw in REG:
         got = [detection.detect_onset_region(a, int(o), **kw) for o in g["reg_onsets"]]

@@ -25,7 +25,7 @@ t0 = time.perf_counter()
 x = synth.c3_stream(secs, C, SR, seed=2)
 print(f"generated {x.shape} in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
 xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
-pipe = FingerprintPipeline(C, NFFT, HOP, SR, NMELS)
+pipe = FingerprintPipeline(C, NFFT, HOP, SR, NMELS, want_power=False)   # config 3: |X|^2 stays on the chip (4 288 B per frame)
 if len(sys.argv) > 3:  # experiments: JSON dict of ofp_detect_tuning fields
     pipe.detector.set_tuning(**json.loads(sys.argv[3]))
 frames = C * pipe.n_frames(x.shape[0])
