@@ -180,9 +180,38 @@ def _synth_worker(job):
     return synth.c2_drums(seconds, C, SR, seed=ident) if kind == "c2" else synth.c4_clip(ident, seconds, C, SR)
 
 
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process AND into every child; with --pmc that library has
+    initialised the GPU before main() runs, and a process that has done so must not start (exec) others on this pool.
+    Round 2's first counter pass of tools/pmc_detect.sh sat in exactly that: eight spawned synthesis workers, each
+    with the counter service attached, were SIGTERMed by Pool.__exit__ while the tool was finalising in them, and the
+    parent then never came out of its own counter-service initialisation (no "HSA version ... initialized" line in
+    gpurun_out/pmc_detect/SQ_INSTS_VALU...log before the 200 s limit).  Under a profiler nothing is spawned."""
+    e = os.environ
+    return any("rocprof" in e.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+        any(k.startswith("ROCPROF") for k in e)
+
+
 def synth_batch(kind, idents, seconds, C, workers):
-    """The clips of one batch (host synthesis, several processes: a C2 clip takes seconds of numpy)."""
+    """The clips of one batch (host synthesis, several processes: a C2 clip takes seconds of numpy).  OFP_SYNTH_CACHE
+    names a directory of per-clip .npy files (filled on first use): a profiled run loads its clips from there instead
+    of synthesising them in child processes (see under_profiler)."""
+    import numpy as np
     jobs = [(kind, int(i), seconds, C) for i in idents]
+    cache = os.environ.get("OFP_SYNTH_CACHE")
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        paths = [Path(cache) / f"{k}_{i}_{s:g}_{c}.npy" for k, i, s, c in jobs]
+        missing = [j for j, p in zip(jobs, paths) if not p.exists()]
+        if missing:
+            made = synth_batch_uncached(missing, 1 if under_profiler() else workers)
+            for j, x in zip(missing, made):
+                np.save(Path(cache) / f"{j[0]}_{j[1]}_{j[2]:g}_{j[3]}.npy", x)
+        return [np.load(p) for p in paths]
+    return synth_batch_uncached(jobs, 1 if under_profiler() else workers)
+
+
+def synth_batch_uncached(jobs, workers):
     if workers <= 1 or len(jobs) == 1:
         return [_synth_worker(j) for j in jobs]
     import multiprocessing as mp
