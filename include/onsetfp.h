@@ -407,6 +407,10 @@ typedef struct ofp_hop_config {
     int32_t max_length, avg_length;
     float ls_max0, ls_minmax, ls_alpha;            /* EMA_MinMaxTracker(max0=10, minmax=0, alpha=0.0005) */
     float oe_min0, oe_minmin, oe_max0, oe_alpha;   /* EMA_MinMaxTracker(min0=0, minmin=0, max0=1, alpha=0.001) */
+    int32_t tg_win_length;  /* > 0: the tempogram frame of the hop as well (realtime/recording.py:313-327, config.py:55:
+                               TG_WIN_LENGTH): autocorrelation of the Hann-windowed last tg_win_length entries of the
+                               normalised onset envelope, lags 0 .. tg_win_length - 1, divided by (its maximum + 1e-10);
+                               needs strength, tg_win_length <= strength_ring.  PARITY UNPINNED like the envelope. */
 } ofp_hop_config;
 typedef struct ofp_hop_session ofp_hop_session; /* opaque */
 int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session** out);
@@ -417,8 +421,8 @@ int ofp_hop_reset(ofp_hop_session* s);
 int ofp_hop_warmup(ofp_hop_session* s, const float* h_x, int64_t n_rows);
 /* One hop, h_hop [B][C].  Outputs (each may be NULL): *n_onsets; h_records [C] with .sample =
  * hop_index * B + delta (audio.py:65) and .clip = 0, in channel order; h_logits [C][mlp outputs];
- * h_mel [C][n_mels]; h_rel [B][C] (needs want_rel); h_strength [4] = {flux, normalised, moving max, moving mean}
- * (needs strength). */
+ * h_mel [C][n_mels]; h_rel [B][C] (needs want_rel); h_strength [4 + tg_win_length] = {flux, normalised, moving max,
+ * moving mean, then the tempogram frame} (needs strength). */
 int ofp_hop_submit(ofp_hop_session* s, const float* h_hop);
 int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records, float* h_logits, float* h_mel,
                     float* h_rel, float* h_strength);

@@ -86,6 +86,7 @@ class HopConfig(ctypes.Structure):
         ("ls_max0", ctypes.c_float), ("ls_minmax", ctypes.c_float), ("ls_alpha", ctypes.c_float),
         ("oe_min0", ctypes.c_float), ("oe_minmin", ctypes.c_float), ("oe_max0", ctypes.c_float),
         ("oe_alpha", ctypes.c_float),
+        ("tg_win_length", ctypes.c_int32),
     ]
 
 

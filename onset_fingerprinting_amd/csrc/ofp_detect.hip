@@ -316,6 +316,22 @@ struct MaxStepEv {
 };
 
 // ---------------------------------------------------------------------------
+// Zero fill of the call's counters and flags by a kernel of our own.  (hipMemsetAsync captured into a hipGraph did
+// not survive replays here: after other launches had gone through the stream between two replays, the captured
+// memset node filled the region with a stale 16-byte pattern -- device pointers of later kernel arguments -- instead
+// of zeros; found by tests/test_gpu_detect.py::test_the_whole_call_is_one_hipgraph..., whose third replay came back
+// with garbage counters.  A kernel node carries its arguments by value.)
+__global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+// ---------------------------------------------------------------------------
 // k_transpose_in: caller audio [clip][N][C] -> planar [clip][C][N]
 __global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
                                                       int64_t N, int C, int TU, int64_t n_w, int64_t Nv) {
@@ -1561,8 +1577,10 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
     double w = c;      // c q^(4 lane): the weight of this lane's LAST element in its first group
     for (int i = 0; i < lane; ++i) w *= q4;
     double acc = 0.0;
-    for (int64_t g = lane; g < ng; g += 64) {
-        float4 v = xs[ng - 1 - g];
+    // Four groups per lane and trip, their loads issued together: one 16-byte load in flight per lane left the pass
+    // latency-bound (a wave moved 1 KB per memory round trip + ~180 fp64 operations: 2.9 TB/s of traffic at full
+    // occupancy on C3's 1.8 G samples, where a copy reaches 4.5+).
+    auto one = [&](float4 v, int64_t g) {
         v.x = ofp_rect_db(v.x, a.floor_db);
         v.y = ofp_rect_db(v.y, a.floor_db);
         v.z = ofp_rect_db(v.z, a.floor_db);
@@ -1571,7 +1589,17 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
         // t = 4 g + 0 for .w, + 1 for .z, + 2 for .y, + 3 for .x
         acc += w * ((double)v.w + q * ((double)v.z + q * ((double)v.y + q * (double)v.x)));
         w *= q256;
+    };
+    int64_t g = lane;
+    for (; g + 192 < ng; g += 256) {
+        const float4 v0 = xs[ng - 1 - g], v1 = xs[ng - 1 - g - 64], v2 = xs[ng - 1 - g - 128], v3 = xs[ng - 1 - g - 192];
+        __builtin_amdgcn_sched_barrier(0);
+        one(v0, g);
+        one(v1, g + 64);
+        one(v2, g + 128);
+        one(v3, g + 192);
     }
+    for (; g < ng; g += 64) one(xs[ng - 1 - g], g);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) P[id] = acc;
 }
@@ -1593,18 +1621,32 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
                      (((int64_t)TU * C) & 3) == 0 && ((g.Nm * C) & 3) == 0;
     if (vec) {
         const int q = nt >> 2;  // float4 groups per channel row
-        for (int i = threadIdx.x; i < q * C; i += 256) {
+        auto at = [&](int i) -> float4* {
             const int c = i / q, t = (i - c * q) << 2;
-            float4* p = reinterpret_cast<float4*>(buf + (clip * C + c) * g.U + u0 + t);
-            float4 v = *p;
+            return reinterpret_cast<float4*>(buf + (clip * C + c) * g.U + u0 + t);
+        };
+        auto one = [&](int i, float4 v) {
+            const int c = i / q, t = (i - c * q) << 2;
             v.x = ofp_rel_linear(v.x, floor_db);
             v.y = ofp_rel_linear(v.y, floor_db);
             v.z = ofp_rel_linear(v.z, floor_db);
             v.w = ofp_rel_linear(v.w, floor_db);
-            *p = v;
+            *at(i) = v;
             float* tl = tile + c * (TU + 1) + t;
             tl[0] = v.x; tl[1] = v.y; tl[2] = v.z; tl[3] = v.w;
+        };
+        // the loads of four groups per thread are issued together (see k_rect_db_sym: one in flight left the pass
+        // latency-bound)
+        int i = threadIdx.x;
+        for (; i + 768 < q * C; i += 1024) {
+            const float4 v0 = *at(i), v1 = *at(i + 256), v2 = *at(i + 512), v3 = *at(i + 768);
+            __builtin_amdgcn_sched_barrier(0);
+            one(i, v0);
+            one(i + 256, v1);
+            one(i + 512, v2);
+            one(i + 768, v3);
         }
+        for (; i < q * C; i += 256) one(i, *at(i));
     } else {
         for (int i = threadIdx.x; i < total; i += 256) {
             const int c = i / nt, t = i - c * nt;
@@ -2532,13 +2574,13 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
                Counters& ctr, int* h_flags, int max_passes, int group, hipStream_t stream, int64_t* passes,
                int64_t* repaired,
                void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, const int*, hipStream_t) = nullptr,
-               int64_t words = 0) {
+               int64_t words = 0, int block = 64) {
     if (words == 0) words = n_threads * 2;  // state words per array
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
     const unsigned grid = (unsigned)cdiv(n_threads, 64);
     int* d_changed = ctr.base;  // pass 0 counts nothing
-    hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
+    hipLaunchKernelGGL(chunk, dim3(grid), dim3(block), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
                        d_changed, (const int*)nullptr);
     OFP_LAUNCH_CHECK(name);
     *passes = 1;
@@ -2552,7 +2594,7 @@ int run_jacobi(const char* name, K chunk, const A& args, int64_t n_threads, int6
     for (int pass = 1;;) {
         if (int rc = ctr.take(group, &d_changed)) return rc;
         for (int q = 0; q < group; ++q) {
-            hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, pass + q, n_threads, (const uint32_t*)prev,
+            hipLaunchKernelGGL(chunk, dim3(grid), dim3(block), 0, stream, args, pass + q, n_threads, (const uint32_t*)prev,
                                next, used, d_changed + q, (const int*)nullptr);
             std::swap(prev, next);
         }
@@ -2598,19 +2640,19 @@ template <class K, class A>
 int run_jacobi_ahead(const char* name, K chunk, const A& args, int64_t n_threads, int64_t n_chunks, uint32_t* used,
                      int* flags, int nv, hipStream_t stream,
                      void (*light_pass)(const A&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, const int*, hipStream_t) = nullptr,
-                     int64_t words = 0) {
+                     int64_t words = 0, int block = 64) {
     if (words == 0) words = n_threads * 2;
     uint32_t* endA = used + words;
     uint32_t* endB = endA + words;
     const unsigned grid = (unsigned)cdiv(n_threads, 64);
-    hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
+    hipLaunchKernelGGL(chunk, dim3(grid), dim3(block), 0, stream, args, 0, n_threads, (const uint32_t*)endB, endA, used,
                        flags, (const int*)nullptr);
     uint32_t* prev = endA;
     uint32_t* next = endB;
     if (n_chunks > 1) {
         for (int j = 1; j <= nv; ++j) {
             const int* gate = j > 1 ? flags + j - 2 : nullptr;
-            hipLaunchKernelGGL(chunk, dim3(grid), dim3(64), 0, stream, args, j, n_threads, (const uint32_t*)prev, next, used,
+            hipLaunchKernelGGL(chunk, dim3(grid), dim3(block), 0, stream, args, j, n_threads, (const uint32_t*)prev, next, used,
                                flags + j - 1, gate);
             std::swap(prev, next);
             if (light_pass && j % 2 == 0 && j < nv) {
@@ -2783,7 +2825,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     if (do_head && timed) OFP_HIP(hipEventRecord(ev[0], stream));
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
         if (phase == 1 || phase == 5 || phase == 6) return OFP_OK;
-        if (phase != 7) OFP_HIP(hipMemsetAsync(d_counts, 0, n_clips * sizeof(int64_t), stream));
+        if (phase != 7) {
+            hipLaunchKernelGGL(k_zero_i64, dim3((unsigned)cdiv(n_clips, 256)), dim3(256), 0, stream, d_counts, n_clips);
+            OFP_LAUNCH_CHECK("k_zero_i64");
+        }
         if (enqueue_only) {
             pend.valid = true;
             pend.empty = true;
@@ -2887,6 +2932,20 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 if (p.manual) info[2] = 0;
             }
             if (hp_open || ar_err || mm_err || d->t.host_verify == -2) {  // (-2: tests exercise this path)
+                if (getenv("OFP_DEBUG_VERIFY")) {
+                    fprintf(stderr, "ofp: repeat host-verified: hp_rounds %d ar_nv %d mm_nv %d open %d %d %d | hr", pend.hp_rounds,
+                            pend.ar_nv, pend.mm_nv, (int)hp_open, (int)ar_err, (int)mm_err);
+                    for (int q = 0; q < 2 * pend.hp_rounds; ++q) fprintf(stderr, " %d", hr[q]);
+                    fprintf(stderr, " | ar");
+                    for (int q = 0; q < 2 * pend.ar_nv; ++q) fprintf(stderr, " %d", pf[q]);
+                    fprintf(stderr, " | mm");
+                    for (int q = 0; q < 2 * pend.mm_nv; ++q) fprintf(stderr, " %d", pf[AHEAD_MAX_PASSES + q]);
+                    fprintf(stderr, "\n");
+                    int dv[8];
+                    (void)hipMemcpy(dv, ws + l.o_hp_rounds, sizeof(dv), hipMemcpyDeviceToHost);
+                    fprintf(stderr, "ofp: device hp rounds now: %d %d %d %d %d %d %d %d  (ws %p, h_flags %p)\n", dv[0], dv[1], dv[2], dv[3],
+                            dv[4], dv[5], dv[6], dv[7], (void*)ws, (void*)d->h_flags);
+                }
                 // the pre-enqueued IIR rounds did not suffice (or a look-back wait gave up): the whole call again,
                 // its passes verified on the host
                 const ofp_detect_tuning keep = d->t;
@@ -2943,7 +3002,11 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
 
     // --- transpose in
     if (do_head) {
-        OFP_HIP(hipMemsetAsync(ws + l.o_zero, 0, (size_t)l.zero_bytes, stream));  // counters, flags: see make_layout
+        {  // counters, flags: see make_layout (regions are 256-byte multiples)
+            const int64_t n16 = l.zero_bytes / 16;
+            hipLaunchKernelGGL(k_zero, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, stream, reinterpret_cast<uint4*>(ws + l.o_zero), n16);
+            OFP_LAUNCH_CHECK("k_zero");
+        }
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
                            stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
         OFP_LAUNCH_CHECK("k_transpose_in");

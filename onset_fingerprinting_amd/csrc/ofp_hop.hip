@@ -49,7 +49,9 @@ struct StrengthArgs {
     float* prev;        // [F/2+1] power spectrum of the previous hop's frame
     float* st;          // [4] ls_max, oe_min, oe_max
     float* ring;        // [n_ring] normalised onset envelope, one entry per hop
-    float* out;         // [4] raw flux, normalised, moving max, moving mean (result block)
+    float* out;         // [4 + tg_len] raw flux, normalised, moving max, moving mean, then the tempogram (result block)
+    int tg_len;         // tempogram window (realtime/recording.py:313-327), 0: off
+    const float* tgw;   // [tg_len] scipy.signal.windows.hann(tg_len) as float32
 };
 
 struct HopArgs {
@@ -317,6 +319,43 @@ __device__ __forceinline__ void hop_strength_body(const HopArgs& a, int64_t h, u
         g.out[2] = m;
         g.out[3] = sm / (float)g.avg_length;
     }
+    // Tempogram frame (realtime/recording.py:313-327): irfft(|rfft(w * onset_env[-W:], n = 2W - 1)|^2)[:W] -- the
+    // transform length 2W - 1 makes the circular correlation the LINEAR autocorrelation of the windowed envelope, so the
+    // W lags are computed as what they are, tg[k] = sum_i y[i] y[i + k] (float32 fma chain over ascending i; the
+    // reference's float FFT round trip agrees to its own rounding), then tg / (max(tg) + 1e-10).  Lags k and W-1-k go
+    // to the same thread: W + 1 products each.  PARITY UNPINNED like the envelope it reads.
+    if (g.tg_len > 0) {
+        const int W = g.tg_len;
+        float* y = red + 64;   // [W] windowed envelope, then [W] the raw lags (LDS reserved by ofp_hop_create)
+        float* tg = y + W;
+        for (int i = tid; i < W; i += WGS) {
+            const int64_t e = h - W + i;   // onset_env[-W + i]; entries before the stream started are the ring's zeros
+            y[i] = e >= 0 ? g.tgw[i] * g.ring[e % g.n_ring] : 0.0f;
+        }
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int k = tid; 2 * k < W; k += WGS) {
+            const int k2 = W - 1 - k;
+            float a0 = 0.0f, a1 = 0.0f;
+            for (int i = 0; i + k < W; ++i) a0 = fmaf(y[i], y[i + k], a0);
+            if (k2 != k)
+                for (int i = 0; i + k2 < W; ++i) a1 = fmaf(y[i], y[i + k2], a1);
+            tg[k] = a0;
+            mx = fmaxf(mx, a0);
+            if (k2 != k) {
+                tg[k2] = a1;
+                mx = fmaxf(mx, a1);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        float m = red[0];
+        for (int w = 1; w < (WGS + 63) / 64; ++w) m = fmaxf(m, red[w]);
+        const float den = m + 1e-10f;
+        for (int k = tid; k < W; k += WGS) g.out[4 + k] = tg[k] / den;
+    }
 }
 
 template <int F>
@@ -387,6 +426,7 @@ struct ofp_hop_session {
     float2* d_twF = nullptr;
     float* d_win = nullptr;
     float* d_wsym = nullptr;
+    float* d_tgw = nullptr;   // tempogram window
     float* d_sg = nullptr;      // onset strength: prev power [bins] | st [4] | ring [n_ring]
     float sg_init[4] = {10.0f, 0.0f, 1.0f, 0.0f};  // ls_max0, oe_min0, oe_max0
     size_t sg_floats = 0;
@@ -549,7 +589,7 @@ int ofp_hop_destroy(ofp_hop_session* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->exec) (void)hipGraphExecDestroy(s->exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
-    void* dev[] = {s->d_state, s->d_hop, s->d_ring, s->d_ctl, s->d_twM, s->d_twF, s->d_win, s->d_wsym, s->d_sg, s->d_fb_i, s->d_fb_w,
+    void* dev[] = {s->d_state, s->d_hop, s->d_ring, s->d_ctl, s->d_twM, s->d_twF, s->d_win, s->d_wsym, s->d_tgw, s->d_sg, s->d_fb_i, s->d_fb_w,
                    s->d_prm, s->d_res};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -578,6 +618,8 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     OFP_REQUIRE(!cfg->strength || (cfg->strength_ring >= 1 && cfg->max_length >= 1 && cfg->avg_length >= 1 &&
                                    cfg->max_length <= cfg->strength_ring && cfg->avg_length <= cfg->strength_ring),
                 "ofp_hop_create: onset strength needs 1 <= max_length, avg_length <= strength_ring");
+    OFP_REQUIRE(cfg->tg_win_length >= 0 && cfg->tg_win_length <= 4096 && (cfg->tg_win_length == 0 || (cfg->strength && cfg->tg_win_length <= cfg->strength_ring && cfg->tg_win_length >= 2)),
+                "ofp_hop_create: the tempogram needs the onset strength and 2 <= tg_win_length <= min(strength_ring, 4096)");
     OFP_REQUIRE(!cfg->mlp || cfg->mlp->plan.dims[0] == cfg->n_mels,
                 "ofp_hop_create: the classifier takes %d inputs, the filterbank has %d bands",
                 cfg->mlp ? cfg->mlp->plan.dims[0] : 0, cfg->n_mels);
@@ -599,7 +641,7 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
     s->o_mel = up8(s->o_logits + (int64_t)C * s->n_out * 4);
     s->o_rel = up8(s->o_mel + (int64_t)C * s->n_mels * 4);
     s->o_sg = up8(s->o_rel + (s->want_rel ? (int64_t)B * C * 4 : 0));
-    s->res_bytes = up8(s->o_sg + 16);
+    s->res_bytes = up8(s->o_sg + 16 + (cfg->strength ? 4 * (int64_t)cfg->tg_win_length : 0));
     const int M = s->n_fft / 2;
     const int st_a = cfg->mlp ? plan.st_a : 0, st_b = cfg->mlp ? plan.st_b : 0;
     s->lds = (size_t)(M + M + 2) * 8 + (size_t)s->n_fft * 4 + (size_t)(M <= 512 ? M + M / 16 : M) * 8 + (size_t)cfg->fb_nnz * 4 +
@@ -690,7 +732,17 @@ int ofp_hop_create(ofp_detector* det, const ofp_hop_config* cfg, ofp_hop_session
         s->sg_init[0] = cfg->ls_max0;
         s->sg_init[1] = cfg->oe_min0;
         s->sg_init[2] = cfg->oe_max0;
-        s->lds_strength = (size_t)(3 * M + M / 16 + 2) * 8 + (size_t)B * C * 4 + 64 * 4;
+        s->lds_strength = (size_t)(3 * M + M / 16 + 2) * 8 + (size_t)B * C * 4 + 64 * 4 + (size_t)2 * cfg->tg_win_length * 4;
+        g.tg_len = cfg->tg_win_length;
+        g.tgw = nullptr;
+        if (cfg->tg_win_length > 0) {  // scipy.signal.windows.hann(W) (symmetric) as float32 (recording.py:250)
+            const int W = cfg->tg_win_length;
+            std::vector<float> w(W);
+            for (int i = 0; i < W; ++i) w[i] = (float)(0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * i / (W - 1)));
+            HOP_TRY(hipMalloc(&s->d_tgw, (size_t)W * 4));
+            HOP_TRY(hipMemcpy(s->d_tgw, w.data(), (size_t)W * 4, hipMemcpyHostToDevice));
+            g.tgw = s->d_tgw;
+        }
         if (s->lds_strength > 160 * 1024) {
             ofp_hop_destroy(s);
             return ofp::fail(OFP_ERR_INVALID, "ofp_hop_create: the hop (%d x %d samples) does not fit the LDS", B, C);
@@ -813,7 +865,7 @@ int ofp_hop_collect(ofp_hop_session* s, int64_t* n_onsets, ofp_onset* h_records,
     if (h_logits && s->n_out) std::memcpy(h_logits, r + s->o_logits, (size_t)s->C * s->n_out * 4);
     if (h_mel) std::memcpy(h_mel, r + s->o_mel, (size_t)s->C * s->n_mels * 4);
     if (h_rel && s->want_rel) std::memcpy(h_rel, r + s->o_rel, (size_t)s->B * s->C * 4);
-    if (h_strength && s->args.sg.enabled) std::memcpy(h_strength, r + s->o_sg, 16);
+    if (h_strength && s->args.sg.enabled) std::memcpy(h_strength, r + s->o_sg, 16 + (size_t)4 * s->args.sg.tg_len);
     return OFP_OK;
 }
 

@@ -80,7 +80,7 @@ class HopSession:
         # per-hop onset strength of the channel mean (realtime/recording.py:273-311; PARITY UNPINNED: its two
         # trackers are loopmate.EMA_MinMaxTracker objects, loopmate is absent; see include/onsetfp.h).
         # onset_strength: None, or a dict with max_length / avg_length (the reference's undefined
-        # config.MAX_LENGTH / AVG_LENGTH) and optionally ring, ls_* / oe_* tracker constants
+        # config.MAX_LENGTH / AVG_LENGTH) and optionally ring, tg_win_length, ls_* / oe_* tracker constants
         self.onset_strength = None
         if onset_strength is not None:
             o = dict(ring=int(np.ceil(max(int(round(ring_seconds * sr)), n_fft) / block_size)), ls_max0=10.0,
@@ -90,6 +90,9 @@ class HopSession:
             cfg.strength_ring, cfg.max_length, cfg.avg_length = int(o["ring"]), int(o["max_length"]), int(o["avg_length"])
             cfg.ls_max0, cfg.ls_minmax, cfg.ls_alpha = o["ls_max0"], o["ls_minmax"], o["ls_alpha"]
             cfg.oe_min0, cfg.oe_minmin, cfg.oe_max0, cfg.oe_alpha = o["oe_min0"], o["oe_minmin"], o["oe_max0"], o["oe_alpha"]
+            # tg_win_length (config.TG_WIN_LENGTH = 1024 upstream): the tempogram frame per hop as well
+            # (recording.py:313-327); needs tg_win_length <= ring
+            cfg.tg_win_length = int(o.get("tg_win_length") or 0)
             self.onset_strength = o
         self.ring_samples = int(cfg.ring_samples)
         h = ctypes.c_void_p()
@@ -102,7 +105,7 @@ class HopSession:
         self._logits = np.zeros((n_signals, max(self.n_out, 1)), dtype=np.float32)
         self._mel = np.zeros((n_signals, n_mels), dtype=np.float32)
         self._rel = np.zeros((block_size, n_signals), dtype=np.float32)
-        self._sg = np.zeros(4, dtype=np.float32)
+        self._sg = np.zeros(4 + (int(cfg.tg_win_length) if onset_strength is not None else 0), dtype=np.float32)
         self.current_index = 0  # audio.py:120
 
     def close(self):
@@ -151,7 +154,9 @@ class HopSession:
                     logits=self._logits.copy() if self.n_out else None, mel=self._mel.copy(),
                     rel=self._rel.copy() if self.want_rel else None,
                     # {flux, normalised, moving max, moving mean} of recording.py:296-311
-                    strength=self._sg.copy() if self.onset_strength else None)
+                    strength=self._sg[:4].copy() if self.onset_strength else None,
+                    # recording.py:313-327 (None unless onset_strength has tg_win_length)
+                    tempogram=self._sg[4:].copy() if self.onset_strength and len(self._sg) > 4 else None)
 
     def __call__(self, hop):
         self.submit(hop)

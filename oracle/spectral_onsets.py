@@ -93,8 +93,10 @@ class HopStrength:
     """RecAnalysis.fft + onset_strength per hop (realtime/recording.py:273-311) on a plain history array.
     max_length / avg_length stand for config.MAX_LENGTH / AVG_LENGTH, which realtime/config.py does not define."""
 
-    def __init__(self, n_fft, n_channels, max_length, avg_length, ring):
+    def __init__(self, n_fft, n_channels, max_length, avg_length, ring, tg_win_length=None):
         from scipy.signal.windows import hann
+        self.tg_win_length = tg_win_length
+        self.tg_window = hann(tg_win_length).astype(np.float32) if tg_win_length else None   # :250
         self.n_fft = n_fft
         self.window = hann(n_fft).astype(np.float32)                       # :249
         self.audio = np.zeros((n_fft, n_channels), np.float32)             # audio[-n_fft:] of the ring buffer
@@ -119,3 +121,12 @@ class HopStrength:
         norm = self.oe.normalize_sample(onset_env)
         self.env = np.concatenate([self.env[1:], [norm]]).astype(np.float32)
         return np.array([onset_env, norm, self.env[-self.max_length:].max(), self.env[-self.avg_length:].mean()])
+
+    def tempogram(self):
+        """realtime/recording.py:313-327 on the envelope history as it stands after __call__: the reference's own
+        expression (transform length tg_pad = 2 W - 1, config.py:56), evaluated in float64."""
+        W = self.tg_win_length
+        P = 2 * W - 1
+        X = np.fft.rfft((self.tg_window * self.env[-W:]).astype(np.float64), n=P)
+        tg = np.fft.irfft(X.real ** 2 + X.imag ** 2, n=P)[:W]
+        return (tg / (tg.max() + 1e-10)).astype(np.float32)

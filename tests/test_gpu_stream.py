@@ -221,6 +221,45 @@ def test_per_hop_onset_strength_matches_the_oracle_restatement(graph, monkeypatc
     sess.close()
 
 
+@pytest.mark.parametrize("graph", ["fused", "nodes"])
+def test_per_hop_tempogram_matches_the_reference_expression(graph, monkeypatch):
+    """The third piece of the per-hop spectral worker (realtime/recording.py:313-327): the tempogram frame of every
+    hop -- autocorrelation of the Hann-windowed last W entries of the normalised onset envelope -- against the
+    reference's own expression (rfft / irfft of length 2 W - 1, float64) on the oracle's envelope history.  PARITY
+    UNPINNED like the envelope (loopmate's trackers are assumed); the GPU sums the lags directly in float32."""
+    from onset_fingerprinting_amd import realtime
+    monkeypatch.setenv("OFP_HOP_GRAPH", graph)
+    C, B, sr, F, W = 2, 128, 48000, 1024, 96
+    x = synth.drum_hits(C, 0.8, sr, seed=41, period=0.07)
+    sess = realtime.HopSession(C, B, sr=sr, n_fft=F, ring_seconds=1.0,
+                               onset_strength=dict(max_length=12, avg_length=40, ring=128, tg_win_length=W))
+    ref = oracle.HopStrength(F, C, 12, 40, 128, tg_win_length=W)
+    worst = 0.0
+    for i in range(len(x) // B):
+        hop = np.ascontiguousarray(x[i * B:(i + 1) * B])
+        got = sess(hop)
+        ref(hop)
+        want = ref.tempogram()
+        assert got["tempogram"].shape == (W,)
+        err = np.abs(got["tempogram"] - want).max()   # (normalised: the largest lag is 1)
+        worst = max(worst, float(err))
+        assert err < RTOL, (i, err)
+        if i > W:
+            assert abs(got["tempogram"][0] - 1.0) < 1e-5
+    assert len(x) // B > 250 and worst > 0
+    sess.close()
+    # the upstream window (config.py:55: TG_WIN_LENGTH = 1024) on a short run
+    sess = realtime.HopSession(C, B, sr=sr, n_fft=F, ring_seconds=1.0,
+                               onset_strength=dict(max_length=12, avg_length=40, ring=1024, tg_win_length=1024))
+    ref = oracle.HopStrength(F, C, 12, 40, 1024, tg_win_length=1024)
+    for i in range(40):
+        hop = np.ascontiguousarray(x[i * B:(i + 1) * B])
+        got = sess(hop)["tempogram"]
+        ref(hop)
+        assert np.abs(got - ref.tempogram()).max() < RTOL
+    sess.close()
+
+
 def test_wide_session_takes_the_five_node_graph_and_the_one_lane_kernel():
     """200 channels x 64 samples: too many channels for the fused kernel's detector workgroup (2 C lanes) and too
     large a block for the phase-split kernel's LDS (3 x B x C floats) -- the session falls back to the five-node
