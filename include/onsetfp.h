@@ -143,6 +143,9 @@ typedef struct ofp_detect_tuning {
                                     speculative passes is chosen for the GPU's share: with k calls in flight each
                                     gets 1/k of the lane budget, i.e. the work-efficient layout of a k times larger
                                     batch instead of the latency layout of a lone call.  Results do not change. */
+    int64_t scan_skip;           /* crossing pass: blocks whose extremes (left by the back-to-linear pass) show that they
+                                    hold no value above `on` and whose last row is below `off` are decided without
+                                    reading their samples: 0 on, < 0 off */
     int64_t host_verify;         /* who drives the verification passes of the three time-parallel stages: 0 (default)
                                     chain-local kernels -- one workgroup owns whole chains and iterates its passes
                                     between workgroup barriers until nothing changes: no host round trip, one launch per

@@ -63,6 +63,7 @@ class DetectTuning(ctypes.Structure):
         ("fuse_db_sums", ctypes.c_int64),
         ("sm_segments", ctypes.c_int64),
         ("concurrent_calls", ctypes.c_int64),
+        ("scan_skip", ctypes.c_int64),
         ("host_verify", ctypes.c_int64),
     ]
 

@@ -1606,14 +1606,31 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
 
 // back to linear (detection.py:753-754), planar in place; the MAIN part is also written to
 // the caller's interleaved [N'][C] array through an LDS tile transpose.
+// With `sum` the pass also leaves, per (main block, channel), the largest and the smallest value of the block
+// (sum_max / sum_minv [clips][nb][C], zeroed by the call's fill; the minimum as 0x7f800000 - bits so that zero is
+// "none yet"): k_block_scan then reads a block's samples only if they can matter (see there).  Values are
+// non-negative (clipped, :754), so their bit patterns order like the values; NaN is ignored on both sides, as a
+// comparison with a threshold ignores it.
 __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
-                                                 float floor_db, int TU) {
-    extern __shared__ float tile[];  // [C][TU+1]
+                                                 float floor_db, int TU, uint32_t* __restrict__ sum_max,
+                                                 uint32_t* __restrict__ sum_minv, int64_t nb) {
+    extern __shared__ float tile[];  // [C][TU+1], then the tile's summaries [2][C][nbt]
     const int C = g.C;
     const int64_t clip = blockIdx.y;
     const int64_t u0 = (int64_t)blockIdx.x * TU;
     const int nt = (int)min<int64_t>(TU, g.U - u0);
     const int total = nt * C;
+    // main blocks this tile touches: j0 .. j0 + nbt - 1 (host: summaries only with B a multiple of 4 and >= 32)
+    const bool sum = sum_max != nullptr && u0 + nt > g.n_wb;
+    const int64_t j0 = max<int64_t>(u0 - g.n_wb, 0) / g.B;
+    const int nbt = TU / g.B + 2;
+    uint32_t* s_max = reinterpret_cast<uint32_t*>(tile + (size_t)C * (TU + 1));
+    uint32_t* s_minv = s_max + C * nbt;
+    const int mbase = (int)(u0 - g.n_wb - j0 * g.B);  // (negative while the tile is still in the warm-up part: j0 = 0 then)
+    if (sum) {
+        for (int i = threadIdx.x; i < 2 * C * nbt; i += 256) s_max[i] = 0u;
+        __syncthreads();
+    }
     // 16-byte accesses on both sides whenever the geometry keeps them aligned (it does for every block size
     // that is a multiple of 4): the planar series in steps of 4 samples, the interleaved output in steps of
     // 4 floats of its [time][channel] order
@@ -1634,6 +1651,15 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
             *at(i) = v;
             float* tl = tile + c * (TU + 1) + t;
             tl[0] = v.x; tl[1] = v.y; tl[2] = v.z; tl[3] = v.w;
+            const int m = mbase + t;  // main row of the group's first value relative to block j0 (the four share a block)
+            if (sum && m >= 0) {
+                float hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+                if (!(hi >= 0.0f)) hi = 0.0f;                 // (all four NaN)
+                if (!(lo >= 0.0f)) lo = __builtin_inff();
+                const int jb = m / g.B;
+                atomicMax(&s_max[c * nbt + jb], ofp_f2u(hi));
+                atomicMax(&s_minv[c * nbt + jb], 0x7f800000u - ofp_f2u(lo));
+            }
         };
         // the loads of four groups per thread are issued together (see k_rect_db_sym: one in flight left the pass
         // latency-bound)
@@ -1656,8 +1682,18 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
             tile[c * (TU + 1) + t] = v;
         }
     }
-    if (!rel_out) return;
     __syncthreads();
+    if (sum) {
+        for (int i = threadIdx.x; i < C * nbt; i += 256) {
+            const int c = i / nbt;
+            const int64_t j = j0 + (i - c * nbt);
+            if (j < nb && (s_max[i] | s_minv[i]) != 0u) {
+                atomicMax(&sum_max[(clip * nb + j) * C + c], s_max[i]);
+                atomicMax(&sum_minv[(clip * nb + j) * C + c], s_minv[i]);
+            }
+        }
+    }
+    if (!rel_out) return;
     float* dst = rel_out + clip * g.Nm * C;
     const int64_t m0 = u0 - g.n_wb;  // main-part row of this tile's first time step (tiles do not straddle n_wb
                                      // unless TU does not divide it: those take the scalar path)
@@ -1699,6 +1735,8 @@ struct ScanArgs {
     int32_t* first_cross;  // [clips][nb][C]: index or -1
     int32_t* last_below;   // [clips][nb][C]: index or -1
     uint32_t* vflag;       // [clips][nb]: some channel has an upward crossing in this block (zeroed by the host)
+    const uint32_t* sum_max;   // [clips][nb][C] largest / smallest value of the block (k_rel_out), or NULL
+    const uint32_t* sum_minv;
 };
 
 // One wave per (chain, block), lanes over the rows of the block (coalesced); the first crossing
@@ -1732,6 +1770,23 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
             off = t2 + mn;  // detection.py:787
         }
         const float* r = a.rel + chain * a.g.U + a.g.n_wb + j * B;
+        if (a.sum_max) {
+            // Most blocks hold neither: no value above `on` (no crossing: first = -1) and a last row below `off`
+            // (last = B - 1) -- decided from the block's extremes and its last sample, without reading the block.
+            // Exact: a crossing needs some v > on; the last row below `off` is row B - 1 whenever that row is below,
+            // and none exists if the smallest value is not below.
+            const float bmax = ofp_u2f(a.sum_max[oi]), bmin = ofp_u2f(0x7f800000u - a.sum_minv[oi]);
+            const float vlast = r[B - 1];
+            const bool scan_first = bmax > on;
+            const bool last_known = vlast < off || !(bmin < off);
+            if (!scan_first && last_known) {
+                if (lane == 0) {
+                    a.first_cross[oi] = -1;
+                    a.last_below[oi] = vlast < off ? B - 1 : -1;
+                }
+                continue;
+            }
+        }
         // detection.py:769: row 0 compares prev_values (float64 copy of the previous block's last
         // row; zeros before the first main block) with the threshold
         float carry = (j == 0) ? 0.0f : r[-1];
@@ -2354,7 +2409,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks, mm_S;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty, o_hp_rounds, o_pass_flags,
+    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty, o_hp_rounds, o_pass_flags, o_sum,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_vtile, o_ltile, o_smseg, o_flags, o_zero, zero_bytes, total;
 };
 
@@ -2544,6 +2599,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_hp_rounds = take(2 * HP_MAX_ROUNDS * 4);  // IIR stage: {stuck, pending} of every round enqueued ahead
     l.o_pass_flags = take(2 * AHEAD_MAX_PASSES * 4);  // follower / tracker stage: change counter of every pass enqueued ahead
     l.o_vflag = take(n_clips * l.nb * 4);
+    l.o_sum = take(2 * n_clips * l.nb * g.C * 4);  // block extremes for the crossing pass (k_rel_out -> k_block_scan)
     l.zero_bytes = o - l.o_zero;
     l.total = o;
     return l;
@@ -3271,9 +3327,18 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
     }
     if (timed) OFP_HIP(hipEventRecord(ev[3], stream));
-    hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), tile_lds, stream, g,
-                       dif, d_rel, p.floor_db, l.tu);
-    OFP_LAUNCH_CHECK("k_rel_out");
+    // block extremes for the crossing pass: whenever the 16-byte path of k_rel_out is taken for every tile (the same
+    // conditions as in the kernel) and a group of four never straddles two blocks
+    const bool use_sum = d->t.scan_skip >= 0 && (g.U & 3) == 0 && (l.tu & 3) == 0 && ((g.n_wb * g.C) & 3) == 0 &&
+                         (((int64_t)l.tu * g.C) & 3) == 0 && ((g.Nm * g.C) & 3) == 0 && (g.B & 3) == 0 && g.B >= 32;
+    uint32_t* sum_max = use_sum ? reinterpret_cast<uint32_t*>(ws + l.o_sum) : nullptr;
+    uint32_t* sum_minv = use_sum ? sum_max + n_clips * l.nb * g.C : nullptr;
+    {
+        const size_t lds = tile_lds + (use_sum ? (size_t)2 * g.C * (l.tu / g.B + 2) * 4 : 0);
+        hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), lds, stream, g, dif, d_rel,
+                           p.floor_db, l.tu, sum_max, sum_minv, l.nb);
+        OFP_LAUNCH_CHECK("k_rel_out");
+    }
     if (timed) OFP_HIP(hipEventRecord(ev[4], stream));
 
     // --- tracker (relative thresholds only; in manual mode its state is never read)
@@ -3345,6 +3410,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     sa.first_cross = reinterpret_cast<int32_t*>(ws + l.o_first);
     sa.last_below = reinterpret_cast<int32_t*>(ws + l.o_last);
     sa.vflag = reinterpret_cast<uint32_t*>(ws + l.o_vflag);
+    sa.sum_max = sum_max;
+    sa.sum_minv = sum_minv;
     {
         const int64_t total = n_clips * l.nb * g.C;
         const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup

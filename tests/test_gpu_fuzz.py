@@ -68,6 +68,8 @@ def random_case(rng):
         tuning["lane_merge"] = int(rng.choice([-1, 1]))
     if rng.random() < 0.5:
         tuning["sm_segments"] = int(rng.choice([1, 1, 2]))   # (clips this short take the sequential machine by default)
+    if rng.random() < 0.3:
+        tuning["scan_skip"] = -1   # the crossing pass reads every block (default: blocks that cannot matter are skipped)
     if rng.random() < 0.25:
         tuning["host_verify"] = 1   # the host-verified pass groups of rounds 1-2 (default: chain-local kernels)
     return x, kw, tuning
