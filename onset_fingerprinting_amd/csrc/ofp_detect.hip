@@ -2988,22 +2988,6 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 if (p.manual) info[2] = 0;
             }
             if (hp_open || ar_err || mm_err || d->t.host_verify == -2) {  // (-2: tests exercise this path)
-                if (getenv("OFP_DEBUG_VERIFY")) {
-                    fprintf(stderr, "ofp: repeat host-verified: hp_rounds %d ar_nv %d mm_nv %d open %d %d %d | hr", pend.hp_rounds,
-                            pend.ar_nv, pend.mm_nv, (int)hp_open, (int)ar_err, (int)mm_err);
-                    for (int q = 0; q < 2 * pend.hp_rounds; ++q) fprintf(stderr, " %d", hr[q]);
-                    fprintf(stderr, " | ar");
-                    for (int q = 0; q < 2 * pend.ar_nv; ++q) fprintf(stderr, " %d", pf[q]);
-                    fprintf(stderr, " | mm");
-                    for (int q = 0; q < 2 * pend.mm_nv; ++q) fprintf(stderr, " %d", pf[AHEAD_MAX_PASSES + q]);
-                    fprintf(stderr, "\n");
-                    int dv[8];
-                    (void)hipMemcpy(dv, ws + l.o_hp_rounds, sizeof(dv), hipMemcpyDeviceToHost);
-                    fprintf(stderr, "ofp: device hp rounds now: %d %d %d %d %d %d %d %d  (ws %p, h_flags %p)\n", dv[0], dv[1], dv[2], dv[3],
-                            dv[4], dv[5], dv[6], dv[7], (void*)ws, (void*)d->h_flags);
-                }
-                // the pre-enqueued IIR rounds did not suffice (or a look-back wait gave up): the whole call again,
-                // its passes verified on the host
                 const ofp_detect_tuning keep = d->t;
                 const ofp_detect_pending keep_pend = pend;  // (a graph that captured this call may be replayed again)
                 d->t.host_verify = 1;
