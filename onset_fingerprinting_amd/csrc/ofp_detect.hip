@@ -333,23 +333,54 @@ __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64
 
 // ---------------------------------------------------------------------------
 // k_transpose_in: caller audio [clip][N][C] -> planar [clip][C][N]
+// Tile rows are TU + 4 floats apart (16-byte aligned rows).  Fast path (full tiles, C and TU powers of two, everything
+// 16-byte aligned: every shape of the BASELINE configs): 16-byte global accesses on both sides and shifts instead of
+// the two integer divisions per element of the general path -- round 3's instruction counters showed this pure data
+// movement issuing as many vector instructions per step (376 M wave-instructions at 16 clips) as the dB pass.
 __global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
                                                       int64_t N, int C, int TU, int64_t n_w, int64_t Nv) {
-    extern __shared__ float tile[];  // [C][TU+1]
+    extern __shared__ float tile[];  // [C][TU+4]
+    const int S = TU + 4;
     const int64_t clip = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * TU;
     const int nt = (int)min<int64_t>(TU, N - t0);
     const float* src = x + (clip * N + t0) * C;
     const int total = nt * C;
+    const bool pow2 = (C & (C - 1)) == 0 && (TU & (TU - 1)) == 0 && TU >= 4;
+    const bool fast = pow2 && nt == TU && ((N * C) & 3) == 0 && (n_w & 3) == 0 && (Nv & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    if (fast) {
+        const int lc = 31 - __clz(C), lq = 31 - __clz(TU) - 2;  // log2 C, log2 (TU / 4)
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        const int total4 = total >> 2;
+        for (int i4 = threadIdx.x; i4 < total4; i4 += 256) {
+            const float4 v = s4[i4];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = 4 * i4 + k;
+                tile[(idx & (C - 1)) * S + (idx >> lc)] = e[k];
+            }
+        }
+        __syncthreads();
+        for (int i4 = threadIdx.x; i4 < total4; i4 += 256) {
+            const int c = i4 >> lq, t = (i4 & ((1 << lq) - 1)) << 2;
+            const float4 v = *reinterpret_cast<const float4*>(&tile[c * S + t]);
+            float* row = xt + (clip * C + c) * Nv;
+            *reinterpret_cast<float4*>(row + n_w + t0 + t) = v;
+            if (t0 + t < n_w) *reinterpret_cast<float4*>(row + t0 + t) = v;  // the warm-up part of the stream (detection.py:70; n_w % 4 == 0)
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < total; i += 256) {
         const int t = i / C, c = i - t * C;
-        tile[c * (TU + 1) + t] = src[i];
+        tile[c * S + t] = src[i];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < total; i += 256) {
         const int c = i / nt, t = i - c * nt;
         float* row = xt + (clip * C + c) * Nv;
-        const float v = tile[c * (TU + 1) + t];
+        const float v = tile[c * S + t];
         row[n_w + t0 + t] = v;
         if (t0 + t < n_w) row[t0 + t] = v;  // the warm-up part of the stream (detection.py:70)
     }
@@ -1614,8 +1645,9 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
 __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
                                                  float floor_db, int TU, uint32_t* __restrict__ sum_max,
                                                  uint32_t* __restrict__ sum_minv, int64_t nb) {
-    extern __shared__ float tile[];  // [C][TU+1], then the tile's summaries [2][C][nbt]
+    extern __shared__ float tile[];  // [C][TU+4], then the tile's summaries [2][C][nbt]
     const int C = g.C;
+    const int S = TU + 4;
     const int64_t clip = blockIdx.y;
     const int64_t u0 = (int64_t)blockIdx.x * TU;
     const int nt = (int)min<int64_t>(TU, g.U - u0);
@@ -1624,7 +1656,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     const bool sum = sum_max != nullptr && u0 + nt > g.n_wb;
     const int64_t j0 = max<int64_t>(u0 - g.n_wb, 0) / g.B;
     const int nbt = TU / g.B + 2;
-    uint32_t* s_max = reinterpret_cast<uint32_t*>(tile + (size_t)C * (TU + 1));
+    uint32_t* s_max = reinterpret_cast<uint32_t*>(tile + (size_t)C * S);
     uint32_t* s_minv = s_max + C * nbt;
     const int mbase = (int)(u0 - g.n_wb - j0 * g.B);  // (negative while the tile is still in the warm-up part: j0 = 0 then)
     if (sum) {
@@ -1638,19 +1670,19 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
                      (((int64_t)TU * C) & 3) == 0 && ((g.Nm * C) & 3) == 0;
     if (vec) {
         const int q = nt >> 2;  // float4 groups per channel row
+        const int lq = (q & (q - 1)) == 0 ? 31 - __clz(q) : -1;  // (a shift when q is a power of two: every full tile)
         auto at = [&](int i) -> float4* {
-            const int c = i / q, t = (i - c * q) << 2;
+            const int c = lq >= 0 ? i >> lq : i / q, t = (i - c * q) << 2;
             return reinterpret_cast<float4*>(buf + (clip * C + c) * g.U + u0 + t);
         };
         auto one = [&](int i, float4 v) {
-            const int c = i / q, t = (i - c * q) << 2;
+            const int c = lq >= 0 ? i >> lq : i / q, t = (i - c * q) << 2;
             v.x = ofp_rel_linear(v.x, floor_db);
             v.y = ofp_rel_linear(v.y, floor_db);
             v.z = ofp_rel_linear(v.z, floor_db);
             v.w = ofp_rel_linear(v.w, floor_db);
             *at(i) = v;
-            float* tl = tile + c * (TU + 1) + t;
-            tl[0] = v.x; tl[1] = v.y; tl[2] = v.z; tl[3] = v.w;
+            *reinterpret_cast<float4*>(tile + c * S + t) = v;
             const int m = mbase + t;  // main row of the group's first value relative to block j0 (the four share a block)
             if (sum && m >= 0) {
                 float hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
@@ -1679,7 +1711,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
             float* p = buf + (clip * C + c) * g.U + u0 + t;
             const float v = ofp_rel_linear(*p, floor_db);
             *p = v;
-            tile[c * (TU + 1) + t] = v;
+            tile[c * S + t] = v;
         }
     }
     __syncthreads();
@@ -1700,13 +1732,14 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     if (vec && (m0 >= 0 || m0 + nt <= 0) && (reinterpret_cast<uintptr_t>(rel_out) & 15u) == 0) {
         if (m0 < 0) return;
         float4* d4 = reinterpret_cast<float4*>(dst + m0 * C);
+        const int lc = (C & (C - 1)) == 0 ? 31 - __clz(C) : -1;
         for (int i = threadIdx.x; i < (total >> 2); i += 256) {
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * i + e;
-                const int t = j / C, c = j - t * C;
-                o[e] = tile[c * (TU + 1) + t];
+                const int t = lc >= 0 ? j >> lc : j / C, c = j - t * C;
+                o[e] = tile[c * S + t];
             }
             d4[i] = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -1715,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     for (int i = threadIdx.x; i < total; i += 256) {
         const int t = i / C, c = i - t * C;
         const int64_t m = u0 + t - g.n_wb;
-        if (m >= 0) dst[m * C + c] = tile[c * (TU + 1) + t];
+        if (m >= 0) dst[m * C + c] = tile[c * S + t];
     }
 }
 
@@ -2898,7 +2931,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const int64_t chains = n_clips * g.C;
     const int64_t n_elem = chains * g.U;
     const unsigned ew_grid = (unsigned)std::min<int64_t>(cdiv(n_elem, 256), 256 * 16);
-    const size_t tile_lds = (size_t)g.C * (l.tu + 1) * sizeof(float);
+    const size_t tile_lds = (size_t)g.C * (l.tu + 4) * sizeof(float);
     const float* rel = dif;  // (the relative envelope overwrites the follower difference in place)
 
     // --- the last stage's arguments, needed by the completion as well (sequential machine as the fall-back)
