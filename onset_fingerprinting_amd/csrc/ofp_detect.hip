@@ -1658,6 +1658,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     const int nbt = TU / g.B + 2;
     uint32_t* s_max = reinterpret_cast<uint32_t*>(tile + (size_t)C * S);
     uint32_t* s_minv = s_max + C * nbt;
+    const int lb = (g.B & (g.B - 1)) == 0 ? 31 - __clz(g.B) : -1;  // (a shift for power-of-two blocks)
     const int mbase = (int)(u0 - g.n_wb - j0 * g.B);  // (negative while the tile is still in the warm-up part: j0 = 0 then)
     if (sum) {
         for (int i = threadIdx.x; i < 2 * C * nbt; i += 256) s_max[i] = 0u;
@@ -1688,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
                 float hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
                 if (!(hi >= 0.0f)) hi = 0.0f;                 // (all four NaN)
                 if (!(lo >= 0.0f)) lo = __builtin_inff();
-                const int jb = m / g.B;
+                const int jb = lb >= 0 ? m >> lb : m / g.B;
                 atomicMax(&s_max[c * nbt + jb], ofp_f2u(hi));
                 atomicMax(&s_minv[c * nbt + jb], 0x7f800000u - ofp_f2u(lo));
             }
@@ -1781,12 +1782,18 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
     const int64_t total = a.n_clips * a.nb * C;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    // item order (clip, c, block): consecutive waves read consecutive blocks of one series
-    for (int64_t id = wave0; id < total; id += n_waves) {
-        const int64_t j = id % a.nb;
-        const int64_t chain = id / a.nb;
-        const int c = (int)(chain % C);
-        const int64_t clip = chain / C;
+    // item order (clip, c, block): consecutive waves read consecutive blocks of one series.  The item's coordinates
+    // are carried along instead of being divided out of `id` every trip (four 64-bit divisions per item were most
+    // of this kernel's vector instructions)
+    int64_t j = wave0 % a.nb, chain = wave0 / a.nb;
+    const int64_t step_j = n_waves % a.nb, step_chain = n_waves / a.nb;
+    for (int64_t id = wave0; id < total; id += n_waves, j += step_j, chain += step_chain) {
+        if (j >= a.nb) {
+            j -= a.nb;
+            chain += 1;
+        }
+        const int64_t clip = (uint32_t)chain / (uint32_t)C;   // (chains < 2^31: one 32-bit division)
+        const int c = (int)(chain - clip * C);
         const int64_t oi = (clip * a.nb + j) * C + c;
         float on, off;
         double on0;
