@@ -14,9 +14,11 @@ Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the
 `--gpus` must then equal WORLD_SIZE (anything else is refused, loudly).
 
 Workloads (BASELINE.json configs):
-  c2  (default at N = 1)  `--clips` (default 16) DISTINCT 8-channel 60 s clips per GPU and step
+  c2  (default at N = 1)  `--clips` (default 48) DISTINCT 8-channel 60 s clips per GPU and step
       (configs[1], the configuration the metric is quoted on, as a batch: one library call processes
-      the clips side by side -- 128 chains).  Every rank owns its own clips: scaling "weak".
+      the clips side by side -- 384 chains, 4.4 GB of audio; rounds 1-2 used 16: the larger batch lets the
+      detector's speculative passes use longer chunks, 145 -> 173 M frames/s with the same command).
+      Every rank owns its own clips: scaling "weak".
       `config.one_clip_per_step` is the same path on ONE clip per step (8 chains, latency-bound).
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
       (configs[3]): total work fixed, scaling "strong".  `config.whole_batch_on_one_gpu` (rank 0, after
@@ -62,7 +64,9 @@ BYTES_FINGERPRINT = 4 * NMELS + 4 * NOUT    # mel + logits out
 BYTES_E2E = BYTES_DETECT + BYTES_SPECTRUM + BYTES_FINGERPRINT  # 4 100 + 192
 # PMC traffic per launch of the dominant kernels (FETCH_SIZE / WRITE_SIZE passes, corrected as the guide's
 # HBM section prescribes) is measured by tools/profile_round.sh, not in this run: the line names its source
-TRAFFIC_FILE = REPO / "profiles" / "r02" / "pmc_traffic_per_kernel.json"
+TRAFFIC_FILE = REPO / "profiles" / "r03" / "pmc_traffic_per_kernel.json"
+SQ_FILE = REPO / "profiles" / "r03" / "pmc_sq_per_kernel.json"   # instruction-level counters per kernel (tools/profile_r3.sh)
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2: the FP32 matrix peak of the guide
 
 
 def free_port():
@@ -292,7 +296,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c2", "c4"], default=None)
-    ap.add_argument("--clips", type=int, default=16, help="c2: distinct clips per GPU and step")
+    ap.add_argument("--clips", type=int, default=48, help="c2: distinct clips per GPU and step (48: 4.4 GB of audio per step, six steps in flight use ~63 %% of the 288 GB)")
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 6 for c2; 6 / 12 for c4 shards of > 128 / <= 128 clips; with two or more in flight the detector runs with its throughput settings lane_merge and hp_dedupe unless --tuning says otherwise)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
@@ -717,7 +721,11 @@ def main():
         achieved = dom_bytes * frames_local / (dom_ms / 1e3) / 1e9
         stage_ms["hp_candidates(part of hp)"] = cand_ms
         traffic, traffic_src = None, None
-        if TRAFFIC_FILE.exists() and workload == "c2" and n_local == 16:  # (the PMC passes were taken at 16 clips per launch)
+        try:
+            pmc_clips = json.load(open(TRAFFIC_FILE.with_name("pmc_meta.json")))["clips"]
+        except (OSError, KeyError, ValueError):
+            pmc_clips = -1
+        if TRAFFIC_FILE.exists() and workload == "c2" and n_local == pmc_clips:  # (counters per launch: only for the batch size they were taken at)
             tj = json.load(open(TRAFFIC_FILE))
             key = {"hp": "k_hp_candidates", "stft_mel": "k_stft_power", "db": "k_rect_db", "rel": "k_rel_out"}.get(dom)
             if key in tj:
@@ -766,6 +774,28 @@ def main():
                                            "note": "the same launch in the same batch step with no OTHER step on the GPU (one step "
                                                    "after the timed region; the launch still runs beside its own step's detector head)"}
             result["stage_ms_alone"] = {k: round(v, 4) for k, v in alone_ms.items()}
+        if SQ_FILE.exists() and workload == "c2" and n_local == pmc_clips and "stft_mel" in stage_ms:
+            # north_star: "MFMA used only for the dense classifier GEMM, evidenced by ... MFMA-busy against chip peak".  The
+            # classifier runs in the epilogue of k_stft_power (19 v_mfma_f32_16x16x4_f32 per tile of 16 frames); instruction and
+            # busy-cycle counts per launch from the PMC pass, the launch duration from this run
+            sq = json.load(open(SQ_FILE)).get("k_stft_power", {})
+            n_mfma, busy = sq.get("SQ_INSTS_MFMA"), sq.get("SQ_VALU_MFMA_BUSY_CYCLES")
+            if n_mfma:
+                flop = n_mfma * 2.0 * 16 * 16 * 4
+                ms_l = stage_ms["stft_mel"]
+                a_ms = alone_ms.get("stft_mel")
+                result["roofline_mfma"] = {
+                    "bound": "mfma", "kernel": kernels["stft_mel"], "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                    "mfma_instructions_per_launch": n_mfma, "flop_per_launch": flop,
+                    "achieved": flop / (ms_l / 1e3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flop / (ms_l / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "alone": ({"achieved": flop / (a_ms / 1e3) / 1e12, "frac": flop / (a_ms / 1e3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "mfma_busy_frac_of_simd_cycles": (busy / (a_ms / 1e3 * 2.4e9 * 1024) if busy else None)}
+                              if a_ms else None),
+                    "source": f"{SQ_FILE.relative_to(REPO)} (rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES, a separate pass of this "
+                              "command) / the launch durations of this run",
+                    "note": "the classifier is 1.4 kflop of the ~32 kflop a frame costs: the matrix cores are busy under 1 % of "
+                            "the launch by construction (SURVEY.md 8d expects 'a small share of time')"}
         if cand_ms > 0 and passes.get("hp_candidate_steps"):
             flop = 17.0 * passes["hp_candidate_steps"]
             tf = flop / (cand_ms / 1e3) / 1e12

@@ -187,9 +187,10 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* det, int64_t n_clips, int
  * longest single launch; or the stages k_hp_seg0 .. k_hp_seg_chunk), 12: IIR steps they execute
  * over all their lanes (17 fp32 operations each), 13: staged candidates only: distinct runs that
  * walked a chunk, of chains * chunks * candidates, 14: 1 if the segmented state machine did not converge within its
- * pre-enqueued passes and the sequential one decided, 15: non-zero if the call was repeated in its host-verified
- * form (1, + 1: the pre-enqueued IIR rounds did not suffice, + 2 / + 4: a look-back wait of the follower / tracker
- * stage gave up)}. */
+ * pre-enqueued passes and the sequential one decided, 15: non-zero if (a part of) the call was repeated with
+ * host-verified passes because what had been enqueued ahead did not converge (1, + 1: the IIR rounds -- the whole call
+ * again; + 2: the follower passes -- again from the follower stage; + 4: the tracker passes -- again from the tracker
+ * stage; the detector then enqueues more passes in its next calls)}. */
 #define OFP_DETECT_INFO_LEN 16
 int ofp_detect_offline(ofp_detector* det, const float* d_x, int64_t n_clips, int64_t n_samples,
                        int64_t warm, float* d_rel, ofp_onset* d_records, int64_t cap_per_clip,

@@ -2486,7 +2486,8 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     int64_t hpL = 8192, hpR = 16, arL = 4096, mmL = 4096;
     if (d->t.hp_chunk <= 0 && d->t.hp_candidates <= 0) {
         if (chains * cdiv(g.V, hpL) * hpR > lane_budget) hpR = 8;  // fewer leave too many chain breaks
-        while (hpL < 65536 && chains * cdiv(g.V, hpL) * hpR > lane_budget) hpL *= 2;
+        // (up to 131 072 since round 3: 64 C2 clips per call, four calls in flight: 163 -> 172 M frames/s over the cap of 65 536)
+        while (hpL < 131072 && chains * cdiv(g.V, hpL) * hpR > lane_budget) hpL *= 2;
     }
     // (followers: their chunk pass is the cheap part, the overlapping warm-up windows the expensive one, so the
     // chunks grow earlier -- at 3/4 of a wave per SIMD; measured on 512 clips x 4 ch: 6.2 -> 4.8 ms)
@@ -2877,9 +2878,12 @@ int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64
 // phase 7: completion of a call that was only enqueued (run_mode 1), after the caller has synchronised.
 // run_mode 0: enqueue, synchronise, complete; 1: enqueue only (phases 0 and 2; nothing in it blocks or reads
 // device results on the host, so the stream may be capturing a hipGraph).
+// from_stage (with phase 2, by the completion's fall-back only): 1 = repeat the call from the follower stage on, 2 = from
+// the tracker stage on -- everything before it (the filtered dB stream / the relative envelope) is in the work space.
 static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64_t N, int64_t warm,
                        float* d_rel, ofp_onset* d_records, int64_t cap, int64_t* d_counts,
-                       void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_, int phase, int run_mode = 0) {
+                       void* d_ws, int64_t ws_bytes, int64_t* h_info, void* stream_, int phase, int run_mode = 0,
+                       int from_stage = 0) {
     OFP_REQUIRE(d && d_counts && d_ws, "ofp_detect_offline: NULL argument");
     OFP_REQUIRE(n_clips >= 1 && N >= 0 && cap >= 0, "ofp_detect_offline: bad sizes");
     OFP_REQUIRE(d_x || N == 0, "ofp_detect_offline: d_x is NULL");
@@ -2918,6 +2922,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (do_head) pend.timed = timed;
         else timed = timed && pend.timed;
     }
+    if (from_stage > 0) timed = pend.timed = false;
     if (do_head && timed) OFP_HIP(hipEventRecord(ev[0], stream));
     if (l.nb == 0) {  // fewer samples than one block: nothing is processed (detection.py:74-75)
         if (phase == 1 || phase == 5 || phase == 6) return OFP_OK;
@@ -3027,7 +3032,11 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 mm_err = ran(pf + AHEAD_MAX_PASSES, pend.mm_nv, &d->mm_pass_hint, &info[2]);
                 if (p.manual) info[2] = 0;
             }
-            if (hp_open || ar_err || mm_err || d->t.host_verify == -2) {  // (-2: tests exercise this path)
+            if (hp_open || ar_err || mm_err || d->t.host_verify <= -2) {  // (-2 / -3 / -4: tests exercise these paths)
+                // What was enqueued ahead did not suffice: the call again from the first stage that has not converged,
+                // its passes verified on the host -- everything (the IIR rounds), from the follower stage on (the dB
+                // stream is final) or from the tracker stage on (the relative envelope is final).
+                const int from = (hp_open || d->t.host_verify == -2) ? 0 : ((ar_err || d->t.host_verify == -3) ? 1 : 2);
                 const ofp_detect_tuning keep = d->t;
                 const ofp_detect_pending keep_pend = pend;  // (a graph that captured this call may be replayed again)
                 d->t.host_verify = 1;
@@ -3035,10 +3044,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 if (ar_err) d->ar_pass_hint = std::min(AHEAD_MAX_PASSES / 2, 2 * pend.ar_nv);
                 if (mm_err) d->mm_pass_hint = std::min(AHEAD_MAX_PASSES / 2, 2 * pend.mm_nv);
                 const int rc = detect_impl(d, d_x, n_clips, N, warm, d_rel, d_records, cap, d_counts, d_ws, ws_bytes, h_info,
-                                           stream_, 0, 0);
+                                           stream_, from == 0 ? 0 : 2, 0, from);
                 d->t = keep;
                 d->pend = keep_pend;
-                if (rc == OFP_OK && h_info) h_info[15] = 1 + (hp_open ? 1 : 0) + (ar_err ? 2 : 0) + (mm_err ? 4 : 0);  // (see include/onsetfp.h)
+                if (rc == OFP_OK && h_info) {
+                    if (from >= 1) h_info[0] = info[0];   // (the stages that were not repeated keep their figures)
+                    if (from >= 2) h_info[1] = info[1];
+                    h_info[15] = 1 + (hp_open ? 1 : 0) + (ar_err ? 2 : 0) + (mm_err ? 4 : 0);  // (see include/onsetfp.h)
+                }
                 return rc;
             }
         }
@@ -3094,8 +3107,20 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     }
     if (phase == 5) return OFP_OK;
 
+    if (from_stage > 0) {  // the words the repeated stages count in / flag must start as zero again
+        auto zero = [&](int64_t off, int64_t bytes) {
+            const int64_t n16 = align_up(bytes, 256) / 16;
+            hipLaunchKernelGGL(k_zero, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, stream, reinterpret_cast<uint4*>(ws + off), n16);
+        };
+        zero(l.o_flags, OFP_N_COUNTERS * 4);
+        zero(l.o_mm_dirty, n_clips * l.mm_chunks * g.C);
+        zero(l.o_vflag, n_clips * l.nb * 4);
+        if (from_stage == 1) zero(l.o_sum, 2 * n_clips * l.nb * g.C * 4);
+        OFP_LAUNCH_CHECK("k_zero");
+    }
+
     // --- hp + dB
-    if (p.hp_enabled) {
+    if (p.hp_enabled && from_stage == 0) {
         HpCand hc;
         hc.st.g = g;
         hc.st.xt = xt;
@@ -3300,7 +3325,9 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     // dB and the per-chunk sums of the closed-form guess in one pass whenever both are wanted and the geometry
     // allows 16-byte groups (otherwise k_rect_db, then k_ar_sym_local reading the dB stream once more)
     const bool db_sym = l.ar_sym && p.hp_enabled && (g.U & 3) == 0 && (l.ar_L & 3) == 0 && d->t.fuse_db_sums >= 0;
-    if (db_sym) {
+    if (from_stage > 0) {
+        // (the dB stream and the sums of the follower guess are in place)
+    } else if (db_sym) {
         hipLaunchKernelGGL(k_rect_db_sym, dim3((unsigned)(chains * l.ar_chunks)), dim3(64), 0, stream, a, xdb,
                            chains * l.ar_chunks, reinterpret_cast<double*>(ws + l.o_ar_P));
         OFP_LAUNCH_CHECK("k_rect_db_sym");
@@ -3312,7 +3339,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     if (timed) OFP_HIP(hipEventRecord(ev[2], stream));
 
     // --- followers
-    {
+    if (from_stage <= 1) {
         const int64_t nt = chains * l.ar_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_ar_state);
         const unsigned grid = (unsigned)cdiv(nt, 64);
@@ -3357,7 +3384,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                          (((int64_t)l.tu * g.C) & 3) == 0 && ((g.Nm * g.C) & 3) == 0 && (g.B & 3) == 0 && g.B >= 32;
     uint32_t* sum_max = use_sum ? reinterpret_cast<uint32_t*>(ws + l.o_sum) : nullptr;
     uint32_t* sum_minv = use_sum ? sum_max + n_clips * l.nb * g.C : nullptr;
-    {
+    if (from_stage <= 1) {
         const size_t lds = tile_lds + (use_sum ? (size_t)2 * g.C * (l.tu / g.B + 2) * 4 : 0);
         hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), lds, stream, g, dif, d_rel,
                            p.floor_db, l.tu, sum_max, sum_minv, l.nb);

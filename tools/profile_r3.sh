@@ -26,21 +26,23 @@ pmc() {  # name, counters..., then -- bench arguments
   rm -rf $O/pmc_$name
 }
 TH='{"lane_merge": 1, "hp_dedupe": 1}'
+CLIPS=${OFP_PROFILE_CLIPS:-48}   # (the bench's default batch: the per-launch counters belong to that size)
+echo "{\"clips\": $CLIPS}" > $O/pmc_meta.json
 echo "== HBM-side traffic per kernel (FETCH_SIZE / WRITE_SIZE, separate passes, one step at a time)"; date
-pmc fetch_c2x16 FETCH_SIZE -- --clips 16 --tuning "$TH"
-pmc write_c2x16 WRITE_SIZE -- --clips 16 --tuning "$TH"
-python3 $ROOT/tools/pmc_traffic.py $O/pmc_fetch_c2x16.csv $O/pmc_write_c2x16.csv > $O/pmc_traffic_per_kernel.json
+pmc fetch_c2 FETCH_SIZE -- --clips $CLIPS --tuning "$TH"
+pmc write_c2 WRITE_SIZE -- --clips $CLIPS --tuning "$TH"
+python3 $ROOT/tools/pmc_traffic.py $O/pmc_fetch_c2.csv $O/pmc_write_c2.csv > $O/pmc_traffic_per_kernel.json
 if [ -z "$QUICK" ]; then
   pmc fetch_c2x1 FETCH_SIZE -- --clips 1
   pmc write_c2x1 WRITE_SIZE -- --clips 1
   python3 $ROOT/tools/pmc_traffic.py $O/pmc_fetch_c2x1.csv $O/pmc_write_c2x1.csv > $O/pmc_traffic_per_kernel_c2x1.json
 fi
-echo "== SQ counters of every kernel of the step (detector + STFT/classifier), 16 clips, one step at a time"; date
-pmc sq_insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -- --clips 16 --tuning "$TH"
-pmc sq_cycles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -- --clips 16 --tuning "$TH"
-pmc sq_vmem SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY -- --clips 16 --tuning "$TH"
-pmc sq_mfma SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES -- --clips 16 --tuning "$TH"
-[ -f $O/pmc_sq_mfma.csv ] || pmc sq_mfma SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES -- --clips 16 --tuning "$TH"
+echo "== SQ counters of every kernel of the step (detector + STFT/classifier), one step at a time"; date
+pmc sq_insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -- --clips $CLIPS --tuning "$TH"
+pmc sq_cycles SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -- --clips $CLIPS --tuning "$TH"
+pmc sq_vmem SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY -- --clips $CLIPS --tuning "$TH"
+pmc sq_mfma SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES -- --clips $CLIPS --tuning "$TH"
+[ -f $O/pmc_sq_mfma.csv ] || pmc sq_mfma SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES -- --clips $CLIPS --tuning "$TH"
 python3 $ROOT/tools/pmc_sq_table.py $O > $O/pmc_sq_per_kernel.json 2> $O/sq_table.err
 if [ -z "$QUICK" ]; then
   echo "== per-hop latency (BASELINE config 5)"; date
@@ -53,7 +55,7 @@ python3 - <<PY
 import json
 t = json.load(open("$O/pmc_traffic_per_kernel.json"))
 tot = sum(v["hbm_mb_per_launch"] * v["calls"] for v in t.values())
-print("PMC MB per 16-clip step (3 steps profiled):", round(tot / 3), {k: (v["calls"], round(v["hbm_mb_per_launch"])) for k, v in list(t.items())[:14]})
+print("PMC MB per step (3 steps profiled):", round(tot / 3), {k: (v["calls"], round(v["hbm_mb_per_launch"])) for k, v in list(t.items())[:14]})
 print(open("$O/kernel_stats_in_flight.json").read()[:1800])
 print(open("$O/pmc_sq_per_kernel.json").read()[:2500])
 PY
