@@ -31,6 +31,10 @@ followers / both tracker words, IIR candidates in stages; small C4 shards also t
 `concurrent_calls`) -- every setting gives the same bytes (tests/test_gpu_pipeline.py).  The K timed steps are bracketed by barriers as the
 contract asks (the pipeline's ramp-up and drain are inside the window); `config.latency_ms_per_step` is what
 one step takes meanwhile.
+`--steps-per-call G` (C4 shards of at most 256 clips: G x clips <= 640 by default, G a divisor of K): the resident
+batches of G consecutive steps go through ONE library call side by side; every step's records are still packed and
+exchanged on their own, in step order (`config.steps_per_call`, `config.calls_in_flight_per_gpu`).  `--inflight`
+then counts calls.
 
 `--rehearsal` (no GPU needed): the launcher, rendezvous, sharding, exchange, max-over-ranks timing and
 JSON line with fabricated onset records instead of GPU work -- the control flow of the N > 1 path for
@@ -298,6 +302,9 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c4"], default=None)
     ap.add_argument("--clips", type=int, default=48, help="c2: distinct clips per GPU and step (48: 4.4 GB of audio per step, six steps in flight use ~63 %% of the 288 GB)")
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 6 for c2; 6 / 12 for c4 shards of > 128 / <= 128 clips; with two or more in flight the detector runs with its throughput settings lane_merge and hp_dedupe unless --tuning says otherwise)")
+    ap.add_argument("--steps-per-call", type=int, default=0, help="c4: consecutive steps whose (distinct) batches ONE library call "
+                    "processes side by side; every step keeps its own exchange (0: small shards are grouped up to ~384 clips per "
+                    "call, by a divisor of --steps; 1: never)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of one clip given to the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra figures (one clip per step, whole batch)")
@@ -363,7 +370,7 @@ def main():
     cap_clip = 4096 if workload == "c2" else 1024      # onset records per clip (C2 has ~950, a C4 clip ~160)
     # records per rank in the exchanged block: the SAME size on every rank (an all-gather of equal blocks),
     # so it is sized for the largest shard
-    n_local_max = n_local if workload == "c2" else -(-C4["clips"] // world)
+    n_local_max = n_local if workload == "c2" else -(-C4["clips"] // (args.shard_of if (world == 1 and args.shard_of > 1) else world))
     cap_block = n_local_max * (1024 if workload == "c2" else 256)
     # steps in flight (measured on one GPU, tools/share_sweep*.sh, ms per step, this build): C2 x 16: 11.5 / 10.6 / 10.6 at
     # 4 / 6 / 8 in flight (C2 x 32: 21.8 / 20.4 at 3 / 4); C4, all 512 clips: 24.9 / 23.8 at 4 / 6; a rank's share
@@ -375,13 +382,25 @@ def main():
         D = 12 if n_local <= 128 else 6
     else:
         D = 6
+    # Steps per call (strong scaling, small shards): a rank's 64 clips are a small call -- twelve of them in flight reach
+    # 115 M frames/s where 512 clips per call reach 155-160 M.  The steps are independent and their batches
+    # are resident before the timed region, so G consecutive steps' batches go through ONE call (G x n_local clips side
+    # by side, ~512-640 clips); each step's records are then packed and exchanged on their own, in step order.  G divides
+    # K so that the timed region is whole calls.
+    G = 1
+    if workload == "c4" and not rehearsal and args.steps_per_call != 1:
+        n_ref = -(-C4["clips"] // (args.shard_of if (world == 1 and args.shard_of > 1) else world))  # the same on every rank
+        lim = args.steps_per_call if args.steps_per_call > 1 else (640 // n_ref if n_ref <= 256 else 1)
+        G = max([g for g in range(1, max(lim, 1) + 1) if args.steps % g == 0] or [1])
+        if G > 1 and args.inflight <= 0:
+            D = 4 if n_local <= 128 else 6   # CALLS in flight (each G steps)
     auto_tuning = {}
     if D >= 2:
         # steps overlap: the detector's throughput setting (fast/slow follower and min/max as one lane per chunk:
         # half the reads of those passes; 16 x C2, four in flight: 116 -> 127 M frames/s; a lone call is slower with it)
         auto_tuning["lane_merge"] = 1
         auto_tuning["hp_dedupe"] = 1   # IIR candidates in stages, duplicate runs removed (a third of the speculative steps)
-    if workload == "c4" and n_local <= 128 and D >= 4:
+    if workload == "c4" and n_local <= 128 and D >= 4 and G == 1:
         # small shards, many calls in flight: each call lays its speculative passes out for a quarter of the
         # GPU instead of as if it were alone (ofp_detect_tuning.concurrent_calls; results do not change)
         auto_tuning["concurrent_calls"] = 4
@@ -432,7 +451,11 @@ def main():
             slots = [make_clips(s) for s in range(D)]
         else:
             slot0 = make_clips(0)
-            slots = [slot0] + [derive(slot0, s) for s in range(1, D)]
+            if G == 1:
+                slots = [slot0] + [derive(slot0, s) for s in range(1, D)]
+            else:  # a call's slot holds the batches of its G steps back to back (all distinct)
+                slots = [(torch.cat([slot0[0] if w * G + i == 0 else derive(slot0, w * G + i)[0] for i in range(G)]).contiguous(),
+                          slot0[1] if w == 0 else None) for w in range(D)]
         exp = json.loads(args.exp) if args.exp else {}
         no_stft = bool(exp.pop("no_stft", False))
         pipes = [FingerprintPipeline(C, NFFT, HOP, SR, NMELS, device=local, cap_per_clip=cap_clip, **exp) for _ in range(D)]
@@ -451,16 +474,28 @@ def main():
             t_in = time.perf_counter()
             with torch.cuda.stream(streams[w]):
                 out = pipes[w].run(slots[w][0], timed=timed)
-                # this rank's onset records as the fixed block the exchange uses (compacted on the device)
-                blk = pack_clips(out["records"], out["counts"], cap_block, clip_offset=clip_lo)
+                # this rank's onset records as the fixed block the exchange uses (compacted on the device); with G steps
+                # per call one block per step, from that step's clips
+                if G == 1:
+                    blk = pack_clips(out["records"], out["counts"], cap_block, clip_offset=clip_lo)
+                else:
+                    blk = [pack_clips(out["records"][i * n_local:(i + 1) * n_local], out["counts"][i * n_local:(i + 1) * n_local],
+                                      cap_block, clip_offset=clip_lo) for i in range(G)]
             streams[w].synchronize()
             return out, blk, time.perf_counter() - t_in
 
         def finish(out, blk, lat, timed):
             t_g = time.perf_counter()
-            gathered = all_gather_blocks(blk)  # ONE collective of fixed-size blocks, no host round trip
+            if G == 1:
+                gathered = all_gather_blocks(blk)  # ONE collective of fixed-size blocks, no host round trip
+            else:
+                gathered = None
+                for b_i in blk:                    # one per step of the call, in step order
+                    g_i = all_gather_blocks(b_i)
+                    if gathered is None:           # (the checks below read the call's FIRST step: its clip 0 is out[...][0])
+                        gathered = g_i
             if timed:
-                gather_acc.append(time.perf_counter() - t_g)
+                gather_acc.append((time.perf_counter() - t_g) / G)
                 st = dict(out["info"]["stage_ms"])
                 st.pop("total")
                 st.update(out["spectral_ms"])
@@ -472,7 +507,7 @@ def main():
         if D == 1:
             def run_steps(n, timed):
                 res = None
-                for _ in range(n):
+                for _ in range(-(-n // G)):
                     res = finish(*run_step(0, timed), timed)
                 return res
         else:
@@ -480,14 +515,15 @@ def main():
             workers = [ThreadPoolExecutor(1) for _ in range(D)]  # worker w runs steps w, w+D, ... in order
 
             def run_steps(n, timed):
-                futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n)]
+                n_calls = -(-n // G)   # (n is a multiple of G in the timed region)
+                futs = [workers[i % D].submit(run_step, i % D, timed) for i in range(n_calls)]
                 res = None
                 for f in futs:  # complete (and exchange) in step order
                     res = finish(*f.result(), timed)
                 return res
 
     # ---- W warm-up steps, then EXACTLY K timed steps between barriers; max over ranks
-    run_steps(max(args.warmup, D if not rehearsal else 1), False)
+    run_steps(max(args.warmup, D * G if not rehearsal else 1), False)
     barrier()
     t0 = time.perf_counter()
     res = run_steps(args.steps, True)
@@ -523,7 +559,7 @@ def main():
     host_clip0 = None
     parity_out = None
     if not rehearsal:
-        host_clip0 = slots[(args.steps - 1) % D][1]  # host copy of clip 0 of the batch the last timed step ran on (c4: slot 0 only)
+        host_clip0 = slots[(args.steps // G - 1) % D][1]  # host copy of clip 0 of the batch the last timed step ran on (c4: slot 0 only)
         if rank == 0 and world == 1 and not args.no_cpu and res is not None:
             # clip 0 of the last TIMED step, taken to the host before anything else reuses the pipelines' output buffers
             o_t = res[0]
@@ -749,7 +785,7 @@ def main():
             "config": dict({"workload": wl, "clips_per_gpu_per_step": n_local, "clips_total_per_step": total_clips,
                             "frames_per_step": frames_total, "frames_per_gpu_per_step": frames_local,
                             "onsets_gathered": int(len(recs)), "ranks_in_exchange": ranks_seen, "backend": backend if world > 1 else "-",
-                            "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": D, "detector_tuning": tuning or "library defaults",
+                            "parallelism": f"clips x{world}", "steps_in_flight_per_gpu": min(D * G, args.steps) if G > 1 else D, "steps_per_call": G, "calls_in_flight_per_gpu": D, "detector_tuning": tuning or "library defaults",
                             "latency_ms_per_step": round(1e3 * float(np.mean(lat_acc)), 3),
                             "exchange_call_ms_per_step": round(1e3 * float(np.mean(gather_acc)), 3)}, **extras, **result_extra),
             "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -306,6 +306,36 @@ def test_two_ranks_on_one_gpu_gather_what_one_process_computes(mods, tmp_path):
 
 
 @pytest.mark.slow
+def test_bench_two_ranks_with_several_steps_per_call(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), both ranks on this
+    one GPU over gloo: each rank's 256-clip shard of C4 goes through the library two steps per call, every step's
+    records are exchanged on their own, and rank 0 prints the one JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OFP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench_py = str(Path(__file__).resolve().parents[1] / "bench.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), bench_py, "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--inflight", "2", "--no-cpu", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "strong" and j["value"] > 0
+    assert c["ranks_in_exchange"] == 2 and c["steps_per_call"] == 2 and c["clips_per_gpu_per_step"] == 256
+    assert c["onsets_gathered"] > 512 * 50  # (a C4 clip has ~140 onsets: both ranks' records arrived)
+
+
+@pytest.mark.slow
 def test_c4_at_its_stated_size_512_clips_on_one_gpu(mods):
     """BASELINE configs[3] at full size on one GPU: 512 clips x 4 ch x 10 s in ONE call (2 048 chains) in the bench's
     throughput settings == the same clips one call each in the default settings (every 8th clip), and 16 sampled

@@ -18,11 +18,12 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); c = j['config']
-        print(round(j['value'] / 1e6, 1), 'M frames/s', round(j['ms_per_step'], 3), 'ms/step, in flight', c.get('steps_in_flight_per_gpu'), c.get('detector_tuning'), 'latency', c.get('latency_ms_per_step'))
+        print(round(j['value'] / 1e6, 1), 'M frames/s', round(j['ms_per_step'], 3), 'ms/step, in flight', c.get('steps_in_flight_per_gpu'), 'steps per call', c.get('steps_per_call'), c.get('detector_tuning'), 'latency', c.get('latency_ms_per_step'))
 " >> $L; }
 case "$PRESET" in
-  c4shards) STEPS=36; WARM=12
-    run --workload c4; run --workload c4 --shard-of 2; run --workload c4 --shard-of 4; run --workload c4 --shard-of 8 ;;
+  c4shards) STEPS=20; WARM=5   # (the driver's K / W)
+    run --workload c4; run --workload c4 --shard-of 2; run --workload c4 --shard-of 4; run --workload c4 --shard-of 8
+    run --workload c4 --shard-of 2 --steps-per-call 1; run --workload c4 --shard-of 4 --steps-per-call 1; run --workload c4 --shard-of 8 --steps-per-call 1 ;;
   inflight) for d in 1 2 4 6 8; do run --inflight $d; done ;;
   *) [ -n "$PRESET" ] && STEPS=$PRESET; [ -n "$3" ] && WARM=$3
     while IFS= read -r line; do [ -n "$line" ] && eval run $line; done ;;
