@@ -152,6 +152,10 @@ typedef struct ofp_detect_tuning {
                                     stage, the call can be captured in a hipGraph; 1 the round-1/2 form: one launch per
                                     pass, the host reads a change counter per group of passes (verify_group,
                                     max_passes apply to this form only).  Results do not change. */
+    int64_t interleaved;         /* throughput layout (lane_merge), C = 4 or 8: the stages work on the caller's interleaved
+                                    arrays instead of planar copies -- tracker, crossing pass and backtracking read the
+                                    `rel` output (no planar copy of it is written).  0 auto (on whenever the conditions
+                                    hold and `rel` is requested), < 0 never, 1 the `rel` side only.  Results do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -65,6 +65,7 @@ class DetectTuning(ctypes.Structure):
         ("concurrent_calls", ctypes.c_int64),
         ("scan_skip", ctypes.c_int64),
         ("host_verify", ctypes.c_int64),
+        ("interleaved", ctypes.c_int64),
     ]
 
 

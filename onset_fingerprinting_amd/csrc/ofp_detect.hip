@@ -176,6 +176,84 @@ __device__ __forceinline__ void walk(const float* ip, float* op, int64_t n, int&
 }
 
 // ---------------------------------------------------------------------------
+// walk_il: the same inner loop over an INTERLEAVED series ([time][channel] rows -- the caller's `rel` output): a lane's
+// samples are CH floats apart and the lanes of a row's channels are neighbours, so a wave's 4-byte load covers whole
+// rows (CH = 8: eight 32-byte rows of eight chunks).  The series may come in two pieces (n0 samples from p0, then n1
+// from p1: the warm-up rows live in a buffer of their own); the joint costs one slow batch per walk.  No output; EV as
+// in walk().  CH is a template parameter so that the PB loads of a batch are one address and PB immediate offsets.
+template <int CH, int PB, bool EV, class F>
+__device__ __forceinline__ void walk_il(const float* p0, int64_t n0, const float* p1, int64_t n1, int& rem, F& f) {
+    constexpr int64_t FAR = (int64_t)1 << 60;
+    auto one = [&](float x) {
+        f(x);
+        if (EV && rem >= 0) {
+            if (rem == 0) f.event();
+            rem -= 1;
+        }
+    };
+    int64_t nb = (n0 + n1) / PB;
+    int tail = (int)((n0 + n1) - nb * PB);
+    if (n0 == 0) {
+        p0 = p1;
+        n0 = FAR;
+    }
+    auto load = [&](float (&v)[PB]) {
+        if (n0 >= PB) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) v[i] = p0[i * CH];
+            p0 += PB * CH;
+            n0 -= PB;
+            if (n0 == 0) {
+                p0 = p1;
+                n0 = FAR;
+            }
+        } else {  // the batch straddles the joint
+            const int k = (int)n0;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) v[i] = i < k ? p0[i * CH] : p1[(i - k) * CH];
+            p0 = p1 + (int64_t)(PB - k) * CH;
+            n0 = FAR;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](const float (&v)[PB]) {
+        if (EV && rem >= 0 && rem < PB) {  // an event falls inside this batch (rare)
+#pragma unroll
+            for (int i = 0; i < PB; ++i) one(v[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) f(v[i]);
+            if (EV && rem >= 0) rem -= PB;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float A[PB], Bv[PB];
+    if (nb >= 1) {
+        load(A);
+        nb -= 1;
+        while (nb >= 2) {
+            load(Bv); run(A);
+            load(A); run(Bv);
+            nb -= 2;
+        }
+        if (nb == 1) {
+            load(Bv); run(A);
+            run(Bv);
+        } else {
+            run(A);
+        }
+    }
+    for (; tail > 0; --tail) {
+        one(*p0);
+        p0 += CH;
+        if (--n0 == 0) {
+            p0 = p1;
+            n0 = FAR;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // step functors (state by value inside; include/ofp_math.h is the definition)
 
 // ofp_df2t4_step with the same operations in the same order, arranged as 2-wide vectors so
@@ -638,6 +716,8 @@ __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_t
 struct MmArgs {
     Geom g;
     const float* rel;  // planar [clip*C + c][U]
+    const float* rel_il;    // the same values as the caller gets them, interleaved [clip][Nm][C] (main part) ...
+    const float* rel_warm;  // ... and [clip][n_wb][C] (warm-up part): what the *_il kernels read instead
     float* thr_mn;     // [clips][nb][C] tracker state after each MAIN block
     float* thr_mx;
     float alpha_min, alpha_max, ialpha_min, ialpha_max, minmin, min0, max0;
@@ -871,6 +951,143 @@ __global__ __launch_bounds__(64) void k_mm_maxpass(MmArgs a, int64_t n_threads, 
     walk<16, 0, false>(a.rel + chain * a.g.U + start, nullptr, min(start + a.L, a.g.U) - start, norem, mo);
     end_next[sidx + 1] = ofp_f2u(mo.mx);
     a.dirty[id] = 1;
+    atomicAdd(changed, 1);
+}
+
+// ---- the tracker on the INTERLEAVED envelope (throughput setting, C = 4 or 8 with a `rel` output): the three kernels
+// above with lane = (clip, chunk, channel), channel fastest, reading the rows the caller gets (walk_il) -- the planar
+// copy of `rel` is then never written (one pass over the stream less per call).
+struct IlSrc {
+    const float* p0;
+    int64_t n0;
+    const float* p1;
+    int64_t n1;
+};
+// stream positions [u0, u1) of (clip, c): warm-up rows first, main rows after n_wb
+__device__ __forceinline__ IlSrc mm_il_range(const MmArgs& a, int64_t clip, int c, int64_t u0, int64_t u1) {
+    const int64_t nw = a.g.n_wb, C = a.g.C;
+    IlSrc s;
+    s.n0 = max<int64_t>(min(u1, nw) - u0, 0);
+    s.p0 = a.rel_warm + (clip * nw + min(u0, nw)) * C + c;
+    s.n1 = (u1 - u0) - s.n0;
+    s.p1 = a.rel_il + (clip * a.g.Nm + (max(u0, nw) - nw)) * C + c;
+    return s;
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_mm_warm_il(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+    OFP_LATENCY_BOUND_KERNEL();
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int64_t n_groups = cdiv(a.n_chunks, a.S);
+    const int c = (int)(id % CH);
+    const int64_t r = id / CH;
+    const int64_t g = r % n_groups;
+    const int64_t clip = r / n_groups;
+    const int64_t chain = clip * CH + c;
+    const int64_t k0 = g * a.S;
+    const int64_t start = k0 * a.L;
+    int norem = -1;
+    const int64_t ws = max<int64_t>(start - a.W, 0);
+    MmStep s{ws > 0 ? __builtin_inff() : a.min0, ws > 0 ? 0.0f : a.max0, a.minmin, v2f{a.ialpha_min, a.ialpha_max},
+             v2f{a.alpha_min, a.alpha_max}, nullptr, nullptr, 0, 0, nullptr};
+    IlSrc q = mm_il_range(a, clip, c, ws, start);
+    walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+    used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(s.mn);
+    used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(s.mx);
+    for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
+        q = mm_il_range(a, clip, c, (k - 1) * a.L, k * a.L);
+        walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+        used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.mn);
+        used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.mx);
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_mm_chunk_il(MmArgs a, int pass, int64_t n_threads,
+                                                    const uint32_t* __restrict__ end_prev,
+                                                    uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                    int* changed, const int* gate) {
+    OFP_LATENCY_BOUND_KERNEL();
+    if (gate && *gate == 0) return;  // (see k_ar_chunk)
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int c = (int)(id % CH);
+    const int64_t r = id / CH;
+    const int64_t k = r % a.n_chunks;
+    const int64_t clip = r / a.n_chunks;
+    const int64_t chain = clip * CH + c;
+    const int64_t did = chain * a.n_chunks + k;  // (the index the planar kernels call `id`)
+    const int64_t start = k * a.L;
+    const int64_t end = min(start + a.L, a.g.U);
+    const int64_t sidx = did * 2;
+    uint32_t i0 = used[sidx], i1 = used[sidx + 1];
+    if (pass > 0) {
+        if (k == 0) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
+        const bool redo = a.dirty[did] != 0;  // a light pass changed this chunk's starting max
+        if (p0 == i0 && p1 == i1 && !redo) {
+            end_next[sidx] = end_prev[sidx];
+            end_next[sidx + 1] = end_prev[sidx + 1];
+            return;
+        }
+        a.dirty[did] = 0;
+        i0 = p0;
+        i1 = p1;
+        used[sidx] = i0;
+        used[sidx + 1] = i1;
+        atomicAdd(changed, 1);
+    }
+    int rem;
+    const int64_t m = start - a.g.n_wb;  // position in the main part (negative: still warm part)
+    int64_t j = 0;
+    if (m >= 0) {
+        j = m / a.g.B;
+        rem = (int)(a.g.B - 1 - (m - j * a.g.B));
+    } else {
+        rem = (int)min<int64_t>(-m + a.g.B - 1, 0x7fffffff);
+    }
+    const int64_t oi = (clip * a.nb + j) * CH + c;
+    MmStep s{ofp_u2f(i0), ofp_u2f(i1), a.minmin, v2f{a.ialpha_min, a.ialpha_max}, v2f{a.alpha_min, a.alpha_max},
+             a.thr_mn + oi, a.thr_mx + oi, CH, a.g.B, &rem};
+    const IlSrc q = mm_il_range(a, clip, c, start, end);
+    walk_il<CH, 32, true>(q.p0, q.n0, q.p1, q.n1, rem, s);
+    end_next[sidx] = ofp_f2u(s.mn);
+    end_next[sidx + 1] = ofp_f2u(s.mx);
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_mm_maxpass_il(MmArgs a, int64_t n_threads, const uint32_t* __restrict__ end_prev,
+                                                      uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
+                                                      int* changed, const int* gate) {
+    OFP_LATENCY_BOUND_KERNEL();
+    if (gate && *gate == 0) return;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_threads) return;
+    const int c = (int)(id % CH);
+    const int64_t r = id / CH;
+    const int64_t k = r % a.n_chunks;
+    const int64_t clip = r / a.n_chunks;
+    const int64_t did = (clip * CH + c) * a.n_chunks + k;
+    const int64_t sidx = did * 2;
+    end_next[sidx] = end_prev[sidx];  // the min is not touched here
+    if (k == 0 || used[sidx + 1] == end_prev[sidx - 1]) {
+        end_next[sidx + 1] = end_prev[sidx + 1];
+        return;
+    }
+    const uint32_t t = end_prev[sidx - 1];
+    used[sidx + 1] = t;
+    MaxStep mo{ofp_u2f(t), a.ialpha_max, a.alpha_max};
+    int norem = -1;
+    const int64_t start = k * a.L;
+    const IlSrc q = mm_il_range(a, clip, c, start, min(start + a.L, a.g.U));
+    walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, mo);
+    end_next[sidx + 1] = ofp_f2u(mo.mx);
+    a.dirty[did] = 1;
     atomicAdd(changed, 1);
 }
 
@@ -1644,7 +1861,10 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
 // comparison with a threshold ignores it.
 __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
                                                  float floor_db, int TU, uint32_t* __restrict__ sum_max,
-                                                 uint32_t* __restrict__ sum_minv, int64_t nb) {
+                                                 uint32_t* __restrict__ sum_minv, int64_t nb, float* __restrict__ rel_warm,
+                                                 int planar) {
+    // rel_warm: the rows of the warm-up part in the output's interleaved order ([clip][n_wb][C]), for the tracker's
+    // *_il kernels; planar = 0: the planar series are not written back (nothing reads them then)
     extern __shared__ float tile[];  // [C][TU+4], then the tile's summaries [2][C][nbt]
     const int C = g.C;
     const int S = TU + 4;
@@ -1682,7 +1902,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
             v.y = ofp_rel_linear(v.y, floor_db);
             v.z = ofp_rel_linear(v.z, floor_db);
             v.w = ofp_rel_linear(v.w, floor_db);
-            *at(i) = v;
+            if (planar) *at(i) = v;
             *reinterpret_cast<float4*>(tile + c * S + t) = v;
             const int m = mbase + t;  // main row of the group's first value relative to block j0 (the four share a block)
             if (sum && m >= 0) {
@@ -1711,7 +1931,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
             const int c = i / nt, t = i - c * nt;
             float* p = buf + (clip * C + c) * g.U + u0 + t;
             const float v = ofp_rel_linear(*p, floor_db);
-            *p = v;
+            if (planar) *p = v;
             tile[c * S + t] = v;
         }
     }
@@ -1728,11 +1948,12 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
     }
     if (!rel_out) return;
     float* dst = rel_out + clip * g.Nm * C;
+    float* dstw = rel_warm ? rel_warm + clip * g.n_wb * C : nullptr;
     const int64_t m0 = u0 - g.n_wb;  // main-part row of this tile's first time step (tiles do not straddle n_wb
                                      // unless TU does not divide it: those take the scalar path)
     if (vec && (m0 >= 0 || m0 + nt <= 0) && (reinterpret_cast<uintptr_t>(rel_out) & 15u) == 0) {
-        if (m0 < 0) return;
-        float4* d4 = reinterpret_cast<float4*>(dst + m0 * C);
+        if (m0 < 0 && !dstw) return;
+        float4* d4 = reinterpret_cast<float4*>(m0 < 0 ? dstw + u0 * C : dst + m0 * C);
         const int lc = (C & (C - 1)) == 0 ? 31 - __clz(C) : -1;
         for (int i = threadIdx.x; i < (total >> 2); i += 256) {
             float o[4];
@@ -1750,6 +1971,7 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
         const int t = i / C, c = i - t * C;
         const int64_t m = u0 + t - g.n_wb;
         if (m >= 0) dst[m * C + c] = tile[c * S + t];
+        else if (dstw) dstw[(u0 + t) * C + c] = tile[c * S + t];
     }
 }
 
@@ -1857,6 +2079,79 @@ __global__ __launch_bounds__(256) void k_block_scan(ScanArgs a) {
             }
         }
         if (lane == 0) {
+            a.first_cross[oi] = first;
+            a.last_below[oi] = last;
+            if (first >= 0) a.vflag[clip * a.nb + j] = 1u;  // every writer stores the same value
+        }
+    }
+}
+
+// The same pass over the INTERLEAVED envelope ([clip][Nm][CH], relative thresholds): one wave per (clip, block), lane =
+// (row of a step, channel) -- a step is 64 / CH rows, one coalesced 256-byte load; the ballots then hold the CH
+// channels bit-interleaved and every lane picks its channel's bits.  A block is read only if one of its channels
+// needs it (same rule as above).
+template <int CH>
+__global__ __launch_bounds__(256) void k_block_scan_il(ScanArgs a, const float* __restrict__ rel_il) {
+    OFP_LATENCY_BOUND_KERNEL();
+    constexpr int RPS = 64 / CH;  // rows per step
+    constexpr unsigned long long CHM = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    const int B = a.g.B;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % CH, rl = lane / CH;
+    const unsigned long long mine = CHM << c;
+    const int64_t total = a.n_clips * a.nb;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float on_c = a.on_f[c], off_c = a.off_f[c];
+    for (int64_t id = wave0; id < total; id += n_waves) {
+        const int64_t clip = id / a.nb, j = id - clip * a.nb;
+        const int64_t oi = (clip * a.nb + j) * CH + c;
+        const float mn = a.thr_mn[oi], mx = a.thr_mx[oi];
+        const float t1 = mx * on_c;
+        const float on = t1 + mn;  // detection.py:763
+        const double on0 = (double)on;
+        const float t2 = mx * off_c;
+        const float off = t2 + mn;  // detection.py:787
+        const float* r = rel_il + (clip * a.g.Nm + j * B) * CH;  // the block's first row
+        if (a.sum_max) {
+            const float bmax = ofp_u2f(a.sum_max[oi]), bmin = ofp_u2f(0x7f800000u - a.sum_minv[oi]);
+            const float vlast = r[(int64_t)(B - 1) * CH + c];
+            const bool need = bmax > on || !(vlast < off || !(bmin < off));
+            if (!__any(need)) {
+                if (lane < CH) {
+                    a.first_cross[oi] = -1;
+                    a.last_below[oi] = vlast < off ? B - 1 : -1;
+                }
+                continue;
+            }
+        }
+        // detection.py:769: row 0 compares prev_values (the previous block's last row; zeros before the first main block)
+        float carry = (j == 0) ? 0.0f : r[c - CH];
+        int first = -1, last = -1;
+        for (int tb = 0; tb < B; tb += 8 * RPS) {
+            float vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t = tb + q * RPS + rl;
+                vv[q] = t < B ? r[(int64_t)(tb + q * RPS) * CH + lane] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t0 = tb + q * RPS;
+                if (t0 >= B) break;
+                const int t = t0 + rl;
+                const float v = vv[q];
+                float prev = __shfl_up(v, CH);
+                if (rl == 0) prev = carry;
+                const bool below_before = (t == 0) ? ((double)prev < on0) : (prev < on);
+                const unsigned long long mc = __ballot(t < B && v > on && below_before) & mine;
+                const unsigned long long mb = __ballot(t < B && v < off) & mine;
+                if (first < 0 && mc) first = t0 + __builtin_ctzll(mc) / CH;
+                if (mb) last = t0 + (63 - __builtin_clzll(mb)) / CH;
+                carry = __shfl(v, 64 - CH + c);
+            }
+        }
+        if (lane < CH) {
             a.first_cross[oi] = first;
             a.last_below[oi] = last;
             if (first >= 0) a.vflag[clip * a.nb + j] = 1u;  // every writer stores the same value
@@ -2389,6 +2684,7 @@ __global__ __launch_bounds__(64) void k_sm_offsets(SmArgs a, SmSegArgs s) {
 struct BtArgs {
     Geom g;
     const float* rel;  // planar
+    const float* rel_il;  // or the interleaved output [clip][Nm][C] (tracker on the interleaved envelope: no planar copy)
     ofp_onset* records;
     const int64_t* counts;
     int64_t cap, n_clips, N;  // N = backtrack_buffer_size
@@ -2398,6 +2694,7 @@ struct BtArgs {
 __device__ __forceinline__ float bt_at(const BtArgs& a, int64_t clip, int64_t block_end, int64_t i, int c) {
     const int64_t m = block_end - i;  // buffer[-i]
     if (m < 0 || i > a.N) return 0.0f;
+    if (a.rel_il) return a.rel_il[(clip * a.g.Nm + m) * a.g.C + c];
     return a.rel[(clip * a.g.C + c) * a.g.U + a.g.n_wb + m];
 }
 
@@ -2449,7 +2746,7 @@ struct Layout {
     int64_t mm_L, mm_W, mm_chunks, mm_S;
     int tu;  // time steps per transpose tile
     // byte offsets
-    int64_t o_xt, o_xdb, o_dif, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty, o_hp_rounds, o_pass_flags, o_sum,
+    int64_t o_xt, o_xdb, o_dif, o_relw, o_hp_U, o_hp_E, o_hp_sel, o_hp_done, o_hp_M, o_hp_nxt, o_hp_guess, o_hp_ran, o_hp_gs, o_hp_pos, o_hp_mrg, o_hp_runs, o_hp_goff, o_hp_stage_n, o_ar_state, o_ar_P, o_mm_state, o_mm_dirty, o_hp_rounds, o_pass_flags, o_sum,
         o_thr_mn, o_thr_mx, o_first, o_last, o_vflag, o_pc, o_visj, o_vrec, o_nv, o_vtile, o_ltile, o_smseg, o_flags, o_zero, zero_bytes, total;
 };
 
@@ -2594,6 +2891,7 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
     l.o_xt = take(n_clips * g.C * g.Nv * 4 + 64);
     l.o_xdb = take(n_clips * g.C * g.U * 4 + 64);
     l.o_dif = take(n_clips * g.C * g.U * 4 + 64);
+    l.o_relw = take(n_clips * g.C * g.n_wb * 4 + 64);  // interleaved rel of the warm-up rows (tracker on the interleaved envelope)
     {
         const int64_t cc = n_clips * l.hp_chunks * g.C;
         l.o_hp_U = take(cc * (l.hp_R + 1) * 16);
@@ -2945,6 +3243,9 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const unsigned ew_grid = (unsigned)std::min<int64_t>(cdiv(n_elem, 256), 256 * 16);
     const size_t tile_lds = (size_t)g.C * (l.tu + 4) * sizeof(float);
     const float* rel = dif;  // (the relative envelope overwrites the follower difference in place)
+    // tracker, crossing pass and backtracking on the interleaved envelope (see k_mm_warm_il): the planar copy is not written
+    const bool mm_il = d->t.interleaved >= 0 && l.merge && d_rel != nullptr && !p.manual && (g.C == 4 || g.C == 8);
+    float* rel_warm = reinterpret_cast<float*>(ws + l.o_relw);
 
     // --- the last stage's arguments, needed by the completion as well (sequential machine as the fall-back)
     int32_t* va_nv = reinterpret_cast<int32_t*>(ws + l.o_nv);
@@ -2976,6 +3277,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         BtArgs bt;
         bt.g = g;
         bt.rel = rel;
+        bt.rel_il = mm_il ? d_rel : nullptr;
         bt.records = d_records;
         bt.counts = d_counts;
         bt.cap = cap;
@@ -3387,7 +3689,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     if (from_stage <= 1) {
         const size_t lds = tile_lds + (use_sum ? (size_t)2 * g.C * (l.tu / g.B + 2) * 4 : 0);
         hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), lds, stream, g, dif, d_rel,
-                           p.floor_db, l.tu, sum_max, sum_minv, l.nb);
+                           p.floor_db, l.tu, sum_max, sum_minv, l.nb, mm_il ? rel_warm : nullptr, mm_il ? 0 : 1);
         OFP_LAUNCH_CHECK("k_rel_out");
     }
     if (timed) OFP_HIP(hipEventRecord(ev[4], stream));
@@ -3399,6 +3701,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         MmArgs a;
         a.g = g;
         a.rel = rel;
+        a.rel_il = d_rel;
+        a.rel_warm = rel_warm;
         a.thr_mn = thr_mn;
         a.thr_mx = thr_mx;
         a.alpha_min = p.alpha_min;
@@ -3419,25 +3723,40 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
         {
             const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
-            if (l.merge)
+            if (mm_il && g.C == 8)
+                hipLaunchKernelGGL(k_mm_warm_il<8>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            else if (mm_il)
+                hipLaunchKernelGGL(k_mm_warm_il<4>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            else if (l.merge)
                 hipLaunchKernelGGL(k_mm_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             else
                 hipLaunchKernelGGL(k_mm_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_mm_warm2");
         }
-        auto light = +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch, const int* gate,
-                         hipStream_t st) {
+        using MmLight = void (*)(const MmArgs&, int64_t, const uint32_t*, uint32_t*, uint32_t*, int*, const int*, hipStream_t);
+        const MmLight light_pl = +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch, const int* gate,
+                                     hipStream_t st) {
             const int64_t n = m.n_chains * m.n_chunks;
             hipLaunchKernelGGL(k_mm_maxpass, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
         };
+        const MmLight light_il = +[](const MmArgs& m, int64_t, const uint32_t* ep, uint32_t* en, uint32_t* u, int* ch, const int* gate,
+                                     hipStream_t st) {
+            const int64_t n = m.n_chains * m.n_chunks;
+            if (m.g.C == 8)
+                hipLaunchKernelGGL(k_mm_maxpass_il<8>, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
+            else
+                hipLaunchKernelGGL(k_mm_maxpass_il<4>, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
+        };
+        const MmLight light = mm_il ? light_il : light_pl;
+        const auto mm_chunk_k = mm_il ? (g.C == 8 ? k_mm_chunk_il<8> : k_mm_chunk_il<4>) : (l.merge ? k_mm_chunk_both : k_mm_chunk);
         if (!hv_fm) {
             pend.mm_nv = l.mm_chunks > 1 ? std::max(2, std::min(AHEAD_MAX_PASSES / 2, d->mm_pass_hint)) : 0;
-            if (int rc = run_jacobi_ahead("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a,
+            if (int rc = run_jacobi_ahead("tracker stage", mm_chunk_k, a,
                                           l.merge ? nt : 2 * 64 * cdiv(nt, 64), l.mm_chunks, used, pass_flags + AHEAD_MAX_PASSES,
                                           pend.mm_nv, stream, light, 2 * nt))
                 return rc;
         } else {
-            int rc = run_jacobi("tracker stage", l.merge ? k_mm_chunk_both : k_mm_chunk, a, l.merge ? nt : 2 * 64 * cdiv(nt, 64),
+            int rc = run_jacobi("tracker stage", mm_chunk_k, a, l.merge ? nt : 2 * 64 * cdiv(nt, 64),
                                 l.mm_chunks, used, ctr, d->h_flags,
                                 d->t.max_passes, d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &pend.info[2], &pend.info[3],
                                 light, 2 * nt);
@@ -3466,7 +3785,15 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     {
         const int64_t total = n_clips * l.nb * g.C;
         const unsigned bs_grid = (unsigned)std::min<int64_t>(cdiv(total, 4), 256 * 32);  // 4 waves per workgroup
-        hipLaunchKernelGGL(k_block_scan, dim3(bs_grid), dim3(256), 0, stream, sa);
+        if (mm_il) {
+            const unsigned il_grid = (unsigned)std::min<int64_t>(cdiv(n_clips * l.nb, 4), 256 * 32);
+            if (g.C == 8)
+                hipLaunchKernelGGL(k_block_scan_il<8>, dim3(il_grid), dim3(256), 0, stream, sa, d_rel);
+            else
+                hipLaunchKernelGGL(k_block_scan_il<4>, dim3(il_grid), dim3(256), 0, stream, sa, d_rel);
+        } else {
+            hipLaunchKernelGGL(k_block_scan, dim3(bs_grid), dim3(256), 0, stream, sa);
+        }
         OFP_LAUNCH_CHECK("k_block_scan");
     }
     VisArgs va;

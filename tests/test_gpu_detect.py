@@ -66,6 +66,28 @@ def test_c2_slice_default_tuning(det):
     assert np.array_equal(np.array(c), g["c2_ch"]) and np.array_equal(np.array(o), g["c2_on"])
 
 
+@pytest.mark.parametrize("C", [4, 8])
+@pytest.mark.parametrize("kw", [
+    dict(block_size=256, sr=SR),
+    dict(block_size=100, sr=SR, cooldown=20),                       # rows per block not a power of two, not a multiple of 64 / C
+    dict(block_size=32, sr=SR, hipass_freq=0.0, cooldown=0),
+    dict(block_size=256, sr=SR, backtrack=True, backtrack_buffer_size=512, backtrack_smooth_size=5),
+])
+def test_interleaved_layout_matches_planar_and_oracle(det, C, kw):
+    """Throughput layout with 4 / 8 channels: tracker, crossing pass and backtracking read the caller's interleaved `rel`
+    (warm-up rows from a buffer of their own; walk_il's joint falls inside a chunk, and with the odd chunk length inside
+    a batch) and no planar copy is written.  == the planar layout == the oracle, bit for bit."""
+    x = synth.c2_drums(2.7, C, SR, seed=11 + C)[: 129_003]   # (not a whole number of blocks)
+    for tuning in (dict(lane_merge=1, hp_dedupe=1), dict(lane_merge=1, mm_chunk=1999, mm_warm=5000, mm_span=3),
+                   dict(lane_merge=1, interleaved=-1)):
+        check_clip(det, x, tuning=tuning, **kw)
+    recs, rel, info = det.detect_batch(np.stack([x, x[::-1].copy()]), tuning=dict(lane_merge=1), warm=0, **kw)
+    recs2, rel2, _ = det.detect_batch(np.stack([x, x[::-1].copy()]), tuning=dict(lane_merge=1, interleaved=-1), warm=0, **kw)
+    assert np.array_equal(bits(rel), bits(rel2))
+    for a, b in zip(recs, recs2):
+        assert np.array_equal(a["sample"], b["sample"]) and np.array_equal(a["channel"], b["channel"])
+
+
 @pytest.mark.parametrize("tuning", [
     dict(hp_chunk=1024, hp_warm=2048, ar_chunk=2048, ar_warm=60000, mm_chunk=4096, mm_warm=50000),
     # no speculative warm-up at all: every chunk starts wrong, the repair passes must fix it

@@ -72,6 +72,8 @@ def random_case(rng):
         tuning["scan_skip"] = -1   # the crossing pass reads every block (default: blocks that cannot matter are skipped)
     if rng.random() < 0.25:
         tuning["host_verify"] = 1   # the host-verified pass groups of rounds 1-2 (default: chain-local kernels)
+    if rng.random() < 0.3:
+        tuning["interleaved"] = -1  # planar copies throughout (default: 4 / 8 channels in the merged layout read the interleaved arrays)
     return x, kw, tuning
 
 
