@@ -62,11 +62,18 @@ struct TileCfg {
 // and keeps the frame's raw samples in registers; the next frame shares three quarters of them, and the shift by
 // one hop maps lane tid's pair q + NP/4 onto its pair q -- a rotation inside the lane.  Only the quarter that is new
 // is loaded (two 8-byte loads per lane and frame instead of eight, each sample fetched once instead of four times).
-template <int F, bool MLP, bool SLIDE>
-__global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F == 2048 ? 2 : 3))) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
+// IL (SLIDE on the caller's INTERLEAVED input [clip][time][C], C = 4 or 8 -- no planar copy needed): the frame slots of
+// a workgroup are the C channels of the same run of frames (FPW / C such runs per workgroup), so the new quarter of the
+// next frame is ONE contiguous block of hop x C floats per run, of which every slot's lanes fetch their own channel
+// with 4-byte loads: the C waves touch the same 32-byte sectors at about the same time and share them in the CU's
+// vector cache.  (An LDS stage filled with 16-byte loads and one workgroup barrier per frame was measured too: 5 %
+// slower alone, and its 16 KB drop the classifier variant from two workgroups per CU to one.)
+template <int F, bool MLP, bool SLIDE, bool IL = false>
+__global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F == 2048 ? 2 : (IL ? 4 : 3)))) void k_stft_power(const float* __restrict__ x, int64_t n_samples,
                                                             int C, int hop, int64_t H, int64_t total_frames,
                                                             float* __restrict__ power, MelFuse mf, int64_t planar,
                                                             MlpFuse ml) {
+    static_assert(!IL || SLIDE, "IL is a form of SLIDE");
     using G = Cfg<F>;
     using TC = TileCfg<F>;
     constexpr int M = G::M, T = G::T, FPW = G::FPW;
@@ -156,11 +163,40 @@ __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F ==
     };
     // frame of slot `sub` in iteration `it`.  Plain: the workgroups interleave groups of FPW consecutive frames.
     // SLIDE: workgroup b owns FPW K consecutive frames, slot `sub` the K consecutive ones from b FPW K + sub K.
-    const int64_t n_it = SLIDE ? cdiv(n_groups, (int64_t)gridDim.x)
-                               : (n_groups > (int64_t)blockIdx.x ? cdiv(n_groups - (int64_t)blockIdx.x, (int64_t)gridDim.x) : 0);
+    // IL: a run = the C slots sub / C * C ... of this workgroup; row-frame rf = clip H + h, the same for its C slots
+    const int il_gpw = IL ? FPW / C : 1;                      // runs per workgroup
+    const int il_c = IL ? sub % C : 0, il_g = IL ? sub / C : 0;
+    const int64_t total_rf = IL ? total_frames / C : 0;
+    const int64_t n_it = IL ? cdiv(total_rf, (int64_t)gridDim.x * il_gpw)
+                            : (SLIDE ? cdiv(n_groups, (int64_t)gridDim.x)
+                                     : (n_groups > (int64_t)blockIdx.x ? cdiv(n_groups - (int64_t)blockIdx.x, (int64_t)gridDim.x) : 0));
     auto frame_of = [&](int64_t it) -> int64_t {
+        if (IL) {
+            const int64_t rf = ((int64_t)blockIdx.x * il_gpw + il_g) * n_it + it;
+            if (rf >= total_rf) return total_frames;  // (invalid)
+            const uint32_t clip = (uint32_t)rf / H32, h = (uint32_t)rf - clip * H32;
+            return ((int64_t)clip * C + il_c) * H + h;
+        }
         return SLIDE ? ((int64_t)blockIdx.x * FPW + sub) * n_it + it : ((int64_t)blockIdx.x + it * gridDim.x) * FPW + sub;
     };
+    // IL: the slot's series from frame h on as a buffer resource (base = that address, made a scalar: a slot is a whole
+    // wave for T = 64): a lane's load is then ONE 32-bit offset register plus scalar / immediate parts.  (With plain
+    // pointers the compiler carried a 64-bit address pair per load: 40 more registers than the planar form, one
+    // workgroup per CU instead of two.)
+    auto il_base = [&](uint32_t clip, uint32_t h) -> __amdgpu_buffer_rsrc_t {
+        const int64_t o = ((int64_t)clip * n_samples + (int64_t)h * hop) * C + il_c;
+        float* b = const_cast<float*>(x) + o;
+        if (T == 64) {
+            const uintptr_t u = reinterpret_cast<uintptr_t>(b);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            b = reinterpret_cast<float*>(((uintptr_t)hi << 32) | lo);
+        }
+        return __builtin_amdgcn_make_buffer_rsrc(b, 0, 0x7fffffff, 0x00020000);
+    };
+    auto il_at = [](__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t s_off) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)s_off, 0));
+    };
+
     constexpr int NS = NP / 4;  // SLIDE: pairs per lane that are new in the next frame
     float2 nw[NS > 0 ? NS : 1];
     if constexpr (!SLIDE) fetch(blockIdx.x);
@@ -170,7 +206,41 @@ __global__ __launch_bounds__(Cfg<F>::WG) __attribute__((amdgpu_waves_per_eu(F ==
         const int64_t f = frame_of(it);  // flattened (clip, channel, hop)
         const bool valid = f < total_frames;
         const bool last_it = it + 1 == n_it;
-        if constexpr (SLIDE) {
+        if constexpr (IL) {
+            const uint32_t cc = valid ? (uint32_t)f / H32 : 0u;
+            const uint32_t h = valid ? (uint32_t)f - cc * H32 : 0u;
+            const uint32_t clip = cc / C32;
+            if (!valid) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) nx[q] = make_float2(0.0f, 0.0f);
+            } else if (it == 0 || h == 0) {  // the first frame of this run, or of a clip: all of it, strided
+                const __amdgpu_buffer_rsrc_t src = il_base(clip, h);
+                const uint32_t o = (uint32_t)(8 * tid) * C32;  // the lane's byte offset; the pair index q T goes into the scalar part
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    nx[q] = make_float2(il_at(src, o, (uint32_t)(8 * q * T) * C32), il_at(src, o + 4u * C32, (uint32_t)(8 * q * T) * C32));
+            } else {  // rotate, append the new quarter
+#pragma unroll
+                for (int q = 0; q < NP - NS; ++q) nx[q] = nx[q + NS];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) nx[NP - NS + q] = nw[q];
+            }
+            // the lane's own four samples of the run's next block (hop rows x C channels from row h hop + F on): in flight
+            // during this frame's FFT
+            const bool more = valid && !last_it && h + 1 < H32;
+            if (more) {
+                const __amdgpu_buffer_rsrc_t src = il_base(clip, h);
+                const uint32_t o = (uint32_t)(8 * tid) * C32;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const uint32_t so = (uint32_t)(4 * F + 8 * q * T) * C32;
+                    nw[q] = make_float2(il_at(src, o, so), il_at(src, o + 4u * C32, so));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) nw[q] = make_float2(0.0f, 0.0f);
+            }
+        } else if constexpr (SLIDE) {
             const uint32_t cc = valid ? (uint32_t)f / H32 : 0u;
             const uint32_t h = valid ? (uint32_t)f - cc * H32 : 0u;
             const float2* src = reinterpret_cast<const float2*>(x + (int64_t)cc * planar + (int64_t)h * hop) + tid;
@@ -397,7 +467,7 @@ __global__ __launch_bounds__(256) void k_mfcc(const float* __restrict__ mel, int
     }
 }
 
-template <int F, bool MLP, bool SLIDE>
+template <int F, bool MLP, bool SLIDE, bool IL = false>
 int launch_power_s(const float* x, int64_t n_samples, int C, int hop, int64_t H, int64_t total, float* power,
                    const MelFuse& mf, int64_t planar, const MlpFuse& ml, hipStream_t stream) {
     using G = Cfg<F>;
@@ -415,10 +485,10 @@ int launch_power_s(const float* x, int64_t n_samples, int C, int hop, int64_t H,
     }
     if (getenv("OFP_DEBUG_LDS")) fprintf(stderr, "k_stft_power<%d,%d>: %zu bytes of LDS per workgroup\n", F, (int)MLP, lds);
     static ofp::LdsAttrCache attr;  // (one per instantiation)
-    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_stft_power<F, MLP, SLIDE>), lds, attr)) return rc;
+    if (int rc = ofp::ensure_dynamic_lds(reinterpret_cast<const void*>(k_stft_power<F, MLP, SLIDE, IL>), lds, attr)) return rc;
     int64_t groups = cdiv(total, G::FPW);
     unsigned grid = (unsigned)std::min<int64_t>(groups, 256 * 8);
-    hipLaunchKernelGGL((k_stft_power<F, MLP, SLIDE>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
+    hipLaunchKernelGGL((k_stft_power<F, MLP, SLIDE, IL>), dim3(grid), dim3(G::WG), lds, stream, x, n_samples, C, hop, H, total,
                        power, mf, planar, ml);
     OFP_LAUNCH_CHECK("k_stft_power");
     return OFP_OK;
@@ -432,6 +502,12 @@ int launch_power_t(const float* x, int64_t n_samples, int C, int hop, int64_t H,
     if constexpr (F <= 2048) {
         if (planar && hop * 4 == F && (planar & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && !getenv("OFP_STFT_NO_SLIDE"))
             return launch_power_s<F, MLP, true>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
+    }
+    // the caller's interleaved input with 4 or 8 channels: the same on strided 4-byte loads (see the kernel)
+    if constexpr (F <= 1024) {
+        if (!planar && hop * 4 == F && (C == 4 || C == 8) && Cfg<F>::FPW % C == 0 && (reinterpret_cast<uintptr_t>(x) & 3u) == 0 &&
+            !getenv("OFP_STFT_NO_SLIDE"))
+            return launch_power_s<F, MLP, true, true>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
     }
     return launch_power_s<F, MLP, false>(x, n_samples, C, hop, H, total, power, mf, planar, ml, stream);
 }

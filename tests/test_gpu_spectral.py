@@ -273,3 +273,41 @@ def test_sliding_frames_equal_the_plain_frame_mapping(monkeypatch):
         for a, b in zip(*outs):
             assert torch.equal(a, b), (n_fft, C, n_clips, N)
         assert torch.equal(outs[0][0], data.stft_power_dense(x, n_fft, hop))  # and as the interleaved input gives
+
+
+def test_interleaved_sliding_frames_equal_the_plain_frame_mapping(monkeypatch):
+    """The caller's interleaved input with 4 / 8 channels and hop = n_fft / 4 (k_stft_power<.., SLIDE, IL>): the C frame
+    slots of a run share one block of hop x C new samples per frame, fetched once and handed over through an LDS stage.
+    Same arithmetic, so the same bits as the plain mapping (OFP_STFT_NO_SLIDE) and as the planar sliding form -- for
+    runs that cross clip boundaries, one- and two-frame clips, two runs per workgroup (C = 4; n_fft 256 with C = 8),
+    the classifier epilogue, and an input that is not 16-byte aligned (which takes the plain mapping)."""
+    import torch
+    from onset_fingerprinting_amd import data
+    from onset_fingerprinting_amd.pipeline import seeded_fcnn
+    rng = np.random.default_rng(79)
+    mlp = seeded_fcnn(40, 8).device_mlp(0)
+    for n_fft, C, n_clips, N in ((1024, 8, 5, 30000), (1024, 4, 7, 21000), (1024, 8, 40, 1024), (1024, 4, 9, 1280),
+                                 (1024, 8, 3, 1536), (512, 4, 3, 20000), (512, 8, 2, 9999), (256, 8, 3, 9000),
+                                 (256, 4, 2, 5003), (1024, 8, 2, 300000)):
+        hop = n_fft // 4
+        base = torch.from_numpy(rng.standard_normal(n_clips * N * C + 4).astype(np.float32)).cuda()
+        mb = data.MelBank(48000, n_fft, 40)
+        for off in (0, 1):  # off = 1: the same values 4 bytes further on (not 16-byte aligned)
+            x = base[off:off + n_clips * N * C].view(n_clips, N, C)
+            if off:
+                x.copy_(base[:n_clips * N * C].view(n_clips, N, C).clone())
+            xt = x.transpose(1, 2).contiguous()
+            outs = []
+            for no_slide in (False, True):
+                if no_slide:
+                    monkeypatch.setenv("OFP_STFT_NO_SLIDE", "1")
+                else:
+                    monkeypatch.delenv("OFP_STFT_NO_SLIDE", raising=False)
+                p, m = data.stft_power_mel_dense(x, n_fft, hop, mb)
+                p2, m2, l2 = data.stft_power_mel_mlp_dense(x, n_fft, hop, mb, mlp, want_power=True)
+                outs.append((p.clone(), m.clone(), p2.clone(), m2.clone(), l2.clone()))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b), (n_fft, C, n_clips, N, off)
+            monkeypatch.delenv("OFP_STFT_NO_SLIDE", raising=False)
+            p3, m3 = data.stft_power_mel_dense(x, n_fft, hop, mb, planar=(xt.data_ptr(), N))
+            assert torch.equal(outs[0][0], p3) and torch.equal(outs[0][1], m3)

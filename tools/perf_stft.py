@@ -33,6 +33,7 @@ def main():
         "power (interleaved in)": (lambda: stft_power_dense(x, F, hop, out=P), 4 * hop + 4 * bins),
         "power+mel (planar in)": (lambda: stft_power_mel_dense(x, F, hop, mb, out_power=P, out_mel=M, planar=planar), 4 * hop + 4 * bins + 160),
         "mel only (planar in)": (lambda: stft_power_mel_dense(x, F, hop, mb, out_mel=M, want_power=False, planar=planar), 4 * hop + 160),
+        "power+mel+mlp (interleaved in)": (lambda: stft_power_mel_mlp_dense(x, F, hop, mb, mlp, out_power=P, out_mel=M, out_logits=L, want_power=True), 4 * hop + 4 * bins + 192),
         "power+mel+mlp (planar in)": (lambda: stft_power_mel_mlp_dense(x, F, hop, mb, mlp, out_power=P, out_mel=M, out_logits=L, want_power=True, planar=planar), 4 * hop + 4 * bins + 192),
         "mel+mlp, no power (planar in)": (lambda: stft_power_mel_mlp_dense(x, F, hop, mb, mlp, out_mel=M, out_logits=L, want_power=False, planar=planar), 4 * hop + 192),
         "logits only (planar in)": (lambda: stft_power_mel_mlp_dense(x, F, hop, mb, mlp, out_logits=L, want_power=False, want_mel=False, planar=planar), 4 * hop + 32),
