@@ -152,10 +152,13 @@ typedef struct ofp_detect_tuning {
                                     stage, the call can be captured in a hipGraph; 1 the round-1/2 form: one launch per
                                     pass, the host reads a change counter per group of passes (verify_group,
                                     max_passes apply to this form only).  Results do not change. */
-    int64_t interleaved;         /* throughput layout (lane_merge), C = 4 or 8: the stages work on the caller's interleaved
-                                    arrays instead of planar copies -- tracker, crossing pass and backtracking read the
-                                    `rel` output (no planar copy of it is written).  0 auto (on whenever the conditions
-                                    hold and `rel` is requested), < 0 never, 1 the `rel` side only.  Results do not change. */
+    int64_t interleaved;         /* 4 or 8 channels: stages that work on the caller's interleaved arrays instead of planar
+                                    copies.  `rel` side (throughput layout, lane_merge; `rel` requested): tracker, crossing
+                                    pass and backtracking read the `rel` output, no planar copy of it is written (+7 %
+                                    frames/s in flight).  Input side (staged candidates, high-pass on): the IIR stage reads
+                                    the audio as it is, no planar copy of the input is made -- slower (one 4-byte load per
+                                    step and lane), kept for measurement.  0 auto (the `rel` side whenever its conditions
+                                    hold), < 0 never, 1 the `rel` side, 2 the input side, 3 both.  Results do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */
@@ -306,6 +309,9 @@ int ofp_stft_power_mel_mlp(const float* d_x, int64_t n_clips, int64_t n_samples,
 const float* ofp_detect_planar_input(const ofp_detector* det, int64_t n_clips, int64_t n_samples, int64_t warm,
                                      const void* d_ws);
 int64_t ofp_detect_planar_stride(const ofp_detector* det, int64_t n_clips, int64_t n_samples, int64_t warm);
+/* (both return 0 / NULL when the detector's layout for these sizes works on the caller's interleaved array and makes no
+ *  planar copy -- tuning `interleaved` 2 / 3; pass planar_stride 0 and the caller's array then: with 4 or 8 channels and
+ *  hop = n_fft / 4 the dense STFT reads it almost as efficiently.) */
 
 /* Gathered complex STFT frames (data.py:593-654 semantics are built on this by
  * the Python layer): for each of n_frames (clip, channel, start) triples,

@@ -176,14 +176,12 @@ __device__ __forceinline__ void walk(const float* ip, float* op, int64_t n, int&
 }
 
 // ---------------------------------------------------------------------------
-// walk_il: the same inner loop over an INTERLEAVED series ([time][channel] rows -- the caller's `rel` output): a lane's
-// samples are CH floats apart and the lanes of a row's channels are neighbours, so a wave's 4-byte load covers whole
-// rows (CH = 8: eight 32-byte rows of eight chunks).  The series may come in two pieces (n0 samples from p0, then n1
-// from p1: the warm-up rows live in a buffer of their own); the joint costs one slow batch per walk.  No output; EV as
-// in walk().  CH is a template parameter so that the PB loads of a batch are one address and PB immediate offsets.
+// walk_il: the same inner loop over an INTERLEAVED series ([time][channel] rows -- the caller's audio or `rel` output): a
+// lane's samples are CH floats apart and the lanes of a row's channels are neighbours, so a wave's 4-byte load covers
+// whole rows (CH = 8: eight 32-byte rows of eight chunks).  No output; EV as in walk().  CH is a template parameter so
+// that the PB loads of a batch are ONE address register pair and PB immediate offsets.
 template <int CH, int PB, bool EV, class F>
-__device__ __forceinline__ void walk_il(const float* p0, int64_t n0, const float* p1, int64_t n1, int& rem, F& f) {
-    constexpr int64_t FAR = (int64_t)1 << 60;
+__device__ __forceinline__ void walk_il(const float* ip, int64_t n, int& rem, F& f) {
     auto one = [&](float x) {
         f(x);
         if (EV && rem >= 0) {
@@ -191,29 +189,12 @@ __device__ __forceinline__ void walk_il(const float* p0, int64_t n0, const float
             rem -= 1;
         }
     };
-    int64_t nb = (n0 + n1) / PB;
-    int tail = (int)((n0 + n1) - nb * PB);
-    if (n0 == 0) {
-        p0 = p1;
-        n0 = FAR;
-    }
+    int64_t nb = n / PB;
+    int tail = (int)(n - nb * PB);
     auto load = [&](float (&v)[PB]) {
-        if (n0 >= PB) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) v[i] = p0[i * CH];
-            p0 += PB * CH;
-            n0 -= PB;
-            if (n0 == 0) {
-                p0 = p1;
-                n0 = FAR;
-            }
-        } else {  // the batch straddles the joint
-            const int k = (int)n0;
-#pragma unroll
-            for (int i = 0; i < PB; ++i) v[i] = i < k ? p0[i * CH] : p1[(i - k) * CH];
-            p0 = p1 + (int64_t)(PB - k) * CH;
-            n0 = FAR;
-        }
+        for (int i = 0; i < PB; ++i) v[i] = ip[i * CH];
+        ip += PB * CH;
         __builtin_amdgcn_sched_barrier(0);
     };
     auto run = [&](const float (&v)[PB]) {
@@ -244,12 +225,76 @@ __device__ __forceinline__ void walk_il(const float* p0, int64_t n0, const float
         }
     }
     for (; tail > 0; --tail) {
-        one(*p0);
-        p0 += CH;
-        if (--n0 == 0) {
-            p0 = p1;
-            n0 = FAR;
+        one(*ip);
+        ip += CH;
+    }
+}
+// A range of a series that comes in two pieces (n0 samples from p0, then n1 from p1: the warm-up rows of `rel` live in a
+// buffer of their own; the audio restarts at row 0 after the warm-up).  The pieces run through ONE instantiation of the
+// walk; a range that lies in one piece takes the first trip whichever piece it is, so only the lanes that hold the
+// joint make a wave take both.  (A walk that switched pieces inside its batch loads made the compiler carry a
+// selected address per load: five vector instructions per sample more.)
+template <int CH, int PB, bool EV, class F>
+__device__ __forceinline__ void walk_il2(const float* p0, int64_t n0, const float* p1, int64_t n1, int& rem, F& f) {
+    if (n0 == 0) {
+        p0 = p1;
+        n0 = n1;
+        n1 = 0;
+    }
+#pragma unroll 1
+    for (int piece = 0; piece < 2; ++piece) {
+        const float* p = piece ? p1 : p0;
+        const int64_t n = piece ? n1 : n0;
+        if (n > 0) walk_il<CH, PB, EV>(p, n, rem, f);
+    }
+}
+
+// walk_il with a PLANAR output (the IIR stage on the caller's interleaved audio): PB 4-byte loads per batch, the
+// outputs of four steps leave as one 16-byte store (scalar steps until `op` is 16-byte aligned, and for the tail).
+template <int CH, int PB, class F>
+__device__ __forceinline__ void walk_il_out(const float* ip, float* op, int64_t n, F& f) {
+    while (n > 0 && (reinterpret_cast<uintptr_t>(op) & 15u)) {
+        *op++ = f(*ip);
+        ip += CH;
+        --n;
+    }
+    int64_t nb = n / PB;
+    int tail = (int)(n - nb * PB);
+    auto load = [&](float (&v)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) v[i] = ip[i * CH];
+        ip += PB * CH;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](const float (&v)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PB / 4; ++i) {
+            float4 o;
+            o.x = f(v[4 * i]); o.y = f(v[4 * i + 1]); o.z = f(v[4 * i + 2]); o.w = f(v[4 * i + 3]);
+            reinterpret_cast<float4*>(op)[i] = o;
         }
+        op += PB;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float A[PB], Bv[PB];
+    if (nb >= 1) {
+        load(A);
+        nb -= 1;
+        while (nb >= 2) {
+            load(Bv); run(A);
+            load(A); run(Bv);
+            nb -= 2;
+        }
+        if (nb == 1) {
+            load(Bv); run(A);
+            run(Bv);
+        } else {
+            run(A);
+        }
+    }
+    for (; tail > 0; --tail) {
+        *op++ = f(*ip);
+        ip += CH;
     }
 }
 
@@ -992,12 +1037,12 @@ __global__ __launch_bounds__(64) void k_mm_warm_il(MmArgs a, int64_t n_threads, 
     MmStep s{ws > 0 ? __builtin_inff() : a.min0, ws > 0 ? 0.0f : a.max0, a.minmin, v2f{a.ialpha_min, a.ialpha_max},
              v2f{a.alpha_min, a.alpha_max}, nullptr, nullptr, 0, 0, nullptr};
     IlSrc q = mm_il_range(a, clip, c, ws, start);
-    walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+    walk_il2<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
     used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(s.mn);
     used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(s.mx);
     for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
         q = mm_il_range(a, clip, c, (k - 1) * a.L, k * a.L);
-        walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+        walk_il2<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
         used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.mn);
         used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.mx);
     }
@@ -1055,7 +1100,7 @@ __global__ __launch_bounds__(64) void k_mm_chunk_il(MmArgs a, int pass, int64_t 
     MmStep s{ofp_u2f(i0), ofp_u2f(i1), a.minmin, v2f{a.ialpha_min, a.ialpha_max}, v2f{a.alpha_min, a.alpha_max},
              a.thr_mn + oi, a.thr_mx + oi, CH, a.g.B, &rem};
     const IlSrc q = mm_il_range(a, clip, c, start, end);
-    walk_il<CH, 32, true>(q.p0, q.n0, q.p1, q.n1, rem, s);
+    walk_il2<CH, 32, true>(q.p0, q.n0, q.p1, q.n1, rem, s);
     end_next[sidx] = ofp_f2u(s.mn);
     end_next[sidx + 1] = ofp_f2u(s.mx);
 }
@@ -1085,7 +1130,7 @@ __global__ __launch_bounds__(64) void k_mm_maxpass_il(MmArgs a, int64_t n_thread
     int norem = -1;
     const int64_t start = k * a.L;
     const IlSrc q = mm_il_range(a, clip, c, start, min(start + a.L, a.g.U));
-    walk_il<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, mo);
+    walk_il2<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, mo);
     end_next[sidx + 1] = ofp_f2u(mo.mx);
     a.dirty[did] = 1;
     atomicAdd(changed, 1);
@@ -1096,6 +1141,7 @@ __global__ __launch_bounds__(64) void k_mm_maxpass_il(MmArgs a, int64_t n_thread
 struct HpArgs {
     Geom g;
     const float* xt;  // planar audio [clip*C + c][N]
+    const float* x_il;  // or the caller's interleaved audio [clip][N][C] (kernels instantiated with CH = C: no planar copy)
     float* out;       // planar [clip*C + c][U]
     float b[5], a[5];
     int64_t L, W, n_chunks;
@@ -1103,10 +1149,37 @@ struct HpArgs {
 
 // positions [t0, t1) of the hp stream; the stream<->memory mapping is affine between the
 // breaks n_wb and n_w (detection.py:828-834: the tail of the warm-up passes the filter only)
-template <bool OUT, class F>
+template <bool OUT, int CH = 0, class F>
 __device__ __forceinline__ void hp_span(const HpArgs& a, F& f, int64_t chain, int64_t t0, int64_t t1) {
-    const float* xs = a.xt + chain * a.g.Nv;  // the stream itself (see u_src_planar)
     int norem = -1;
+    if constexpr (CH > 0) {
+        // the caller's interleaved audio: stream position v is row v (v < n_w) or row v - n_w of the clip
+        const int64_t clip = chain / CH;
+        const float* xs = a.x_il + clip * a.g.N * CH + (chain - clip * CH);
+        if (!OUT) {
+            if (t1 > t0) {
+                const int64_t n0 = max<int64_t>(min(t1, a.g.n_w) - t0, 0);
+                walk_il2<CH, 32, false>(xs + t0 * CH, n0, xs + (max(t0, a.g.n_w) - a.g.n_w) * CH, (t1 - t0) - n0, norem, f);
+            }
+            return;
+        }
+        float* os = a.out + chain * a.g.U;
+        int64_t p = t0;
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {  // (pieces as below; each lies on one side of the restart at n_w)
+            const int64_t br = i == 0 ? a.g.n_wb : (i == 1 ? a.g.n_w : t1);
+            const int64_t e = min(max(br, p), t1);
+            if (e > p) {
+                const int64_t u = hp_dst(a.g, p);
+                const float* src = xs + hp_src(a.g, p) * CH;
+                if (u >= 0) walk_il_out<CH, 32>(src, os + u, e - p, f);
+                else walk_il<CH, 32, false>(src, e - p, norem, f);
+            }
+            p = e;
+        }
+        return;
+    }
+    const float* xs = a.xt + chain * a.g.Nv;  // the stream itself (see u_src_planar)
     if (!OUT) {
         if (t1 > t0) walk<8, 0, false>(xs + t0, nullptr, t1 - t0, norem, f);
         return;
@@ -1274,21 +1347,39 @@ struct HpRuns {
     float4* z;       // [n] filter state at the common position of the stage
 };
 
-// stage 0: lane = (chain, chunk j, candidate r), r fastest: from its staggered start to window offset p1
+// stage 0: lane = (chain, chunk j, candidate r), r fastest: from its staggered start to window offset p1.
+// CH > 0 (all staged kernels and k_hp_run): the lanes read the caller's INTERLEAVED audio (hp_span<.., CH>), so the
+// channel is the fastest lane coordinate -- lane = (clip, chunk j, candidate r, channel) here, and the groups are
+// numbered (clip, j, channel) so that the work lists keep the channels of a chunk side by side: a wave's 4-byte loads
+// then cover whole 4 CH-byte rows.
+template <int CH>
 __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg0(HpCand a, HpRuns out, int32_t* __restrict__ off,
                                                               int32_t* __restrict__ cnt, int64_t p1, int64_t n_threads) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     const HpArgs& st = a.st;
     int64_t q = id;
-    const int r = (int)(q % a.R);
-    q /= a.R;
-    const int64_t grp = q;
-    const int64_t j = q % st.n_chunks;
-    const int64_t chain = q / st.n_chunks;
+    int r, c;
+    int64_t grp, j, chain, clip;
     const int C = st.g.C;
-    const int64_t clip = chain / C;
-    const int c = (int)(chain % C);
+    if (CH > 0) {
+        c = (int)(q % CH);
+        q /= CH;
+        r = (int)(q % a.R);
+        q /= a.R;
+        j = q % st.n_chunks;
+        clip = q / st.n_chunks;
+        chain = clip * CH + c;
+        grp = (clip * st.n_chunks + j) * CH + c;
+    } else {
+        r = (int)(q % a.R);
+        q /= a.R;
+        grp = q;
+        j = q % st.n_chunks;
+        chain = q / st.n_chunks;
+        clip = chain / C;
+        c = (int)(chain % C);
+    }
     if (r == 0) {
         const int64_t ci = (clip * st.n_chunks + j) * C + c;
         a.sel[ci] = (j == 0) ? 0 : -1;
@@ -1306,10 +1397,11 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg0(HpCand a, HpRuns ou
     if (a.delta == 0) s.z[0] = (float)r * 0.0009765625f;
     const int64_t w0 = j * st.L - st.W;
     const int64_t ws = max<int64_t>(w0 - (int64_t)r * a.delta, 0);
-    hp_span<false>(st, s, chain, ws, max<int64_t>(w0 + p1, 0));
-    out.grp[id] = (int32_t)grp;
-    out.mask[id] = 1u << r;
-    out.z[id] = make_float4(s.z[0], s.z[1], s.z[2], s.z[3]);
+    hp_span<false, CH>(st, s, chain, ws, max<int64_t>(w0 + p1, 0));
+    const int64_t li = CH > 0 ? grp * a.R + r : id;  // the runs of a group are neighbours in the list (k_hp_dedupe)
+    out.grp[li] = (int32_t)grp;
+    out.mask[li] = 1u << r;
+    out.z[li] = make_float4(s.z[0], s.z[1], s.z[2], s.z[3]);
 }
 
 // between stages: 16 lanes per group, lane i holds run i of the group.  A run whose state equals (bitwise) that of
@@ -1360,32 +1452,34 @@ __global__ __launch_bounds__(256) void k_hp_dedupe(HpRuns in, HpRuns out, int32_
 }
 
 // a middle stage: lane = one distinct run, window offsets [p0, p1)
+template <int CH>
 __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg(HpCand a, HpRuns runs, const int* __restrict__ n_runs,
                                                              int64_t p0, int64_t p1) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *n_runs) return;
     const HpArgs& st = a.st;
     const int64_t grp = runs.grp[id];
-    const int64_t j = grp % st.n_chunks;
-    const int64_t chain = grp / st.n_chunks;
+    const int64_t j = CH > 0 ? (grp / CH) % st.n_chunks : grp % st.n_chunks;
+    const int64_t chain = CH > 0 ? grp / (CH * st.n_chunks) * CH + grp % CH : grp / st.n_chunks;
     HpStep s;
     s.coeffs(st.b, st.a);
     const float4 v = runs.z[id];
     s.z[0] = v.x; s.z[1] = v.y; s.z[2] = v.z; s.z[3] = v.w;
     const int64_t w0 = j * st.L - st.W;
-    hp_span<false>(st, s, chain, max<int64_t>(w0 + p0, 0), max<int64_t>(w0 + p1, 0));
+    hp_span<false, CH>(st, s, chain, max<int64_t>(w0 + p0, 0), max<int64_t>(w0 + p1, 0));
     runs.z[id] = make_float4(s.z[0], s.z[1], s.z[2], s.z[3]);
 }
 
 // the last stage: the chunk itself, with the records of every slot the run stands for
+template <int CH>
 __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg_chunk(HpCand a, HpRuns runs, const int* __restrict__ n_runs) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *n_runs) return;
     const HpArgs& st = a.st;
     const int64_t grp = runs.grp[id];
     const uint32_t mask = runs.mask[id];
-    const int64_t k = grp % st.n_chunks;
-    const int64_t chain = grp / st.n_chunks;
+    const int64_t k = CH > 0 ? (grp / CH) % st.n_chunks : grp % st.n_chunks;
+    const int64_t chain = CH > 0 ? grp / (CH * st.n_chunks) * CH + grp % CH : grp / st.n_chunks;
     const int C = st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
@@ -1410,7 +1504,7 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg_chunk(HpCand a, HpRu
     for (int sb = 0; sb < a.S; ++sb) {
         const int64_t t0 = min(start + sb * Ls, end);
         const int64_t t1 = sb == a.S - 1 ? end : min(start + (sb + 1) * Ls, end);
-        hp_span<false>(st, s, chain, t0, t1);
+        hp_span<false, CH>(st, s, chain, t0, t1);
         record(sb);
     }
 }
@@ -1669,6 +1763,7 @@ __global__ __launch_bounds__(64) void k_hp_resolve(HpCand a) {
 // a chunk that starts from an unmatched state (a break, guessed or not) or whose own slot is the
 // exact re-run has no such states and is run whole by lane 0.
 // -> true if the item left sub-chunks open (an early stop): another round is needed
+template <int CH>
 __device__ __forceinline__ bool hp_run_item(const HpCand& a, int64_t chain, int64_t k, int sb) {
     const HpArgs& st = a.st;
     const int C = st.g.C;
@@ -1720,7 +1815,7 @@ __device__ __forceinline__ bool hp_run_item(const HpCand& a, int64_t chain, int6
     for (int q = q0; q < q1; ++q) {
         const int64_t t0 = pieces ? min(start + q * Ls, end) : start;
         const int64_t t1 = (!pieces || q == a.S - 1) ? end : min(start + (q + 1) * Ls, end);
-        hp_span<true>(st, s, chain, t0, t1);
+        hp_span<true, CH>(st, s, chain, t0, t1);
         if (whole && q + 1 < q1) {
             const uint32_t z0 = ofp_f2u(s.z[0]), z1 = ofp_f2u(s.z[1]), z2 = ofp_f2u(s.z[2]), z3 = ofp_f2u(s.z[3]);
             for (int r = 0; r < a.R; ++r) {
@@ -1763,14 +1858,23 @@ __device__ __forceinline__ bool hp_run_item(const HpCand& a, int64_t chain, int6
     return joined >= 0;  // open sub-chunks: another round
 }
 
+template <int CH>
 __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     OFP_LATENCY_BOUND_KERNEL();
     if (a.prev && a.prev[0] + a.prev[1] == 0) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
+    if (CH > 0) {  // lane = (clip, chunk, sub-chunk, channel): see k_hp_seg0
+        const int c = (int)(id % CH);
+        const int64_t q = id / CH;
+        const int sb = (int)(q % a.S);
+        const int64_t kc = q / a.S;
+        if (hp_run_item<CH>(a, kc / a.st.n_chunks * CH + c, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
+        return;
+    }
     const int sb = (int)(id % a.S);
     const int64_t kc = id / a.S;
-    if (hp_run_item(a, kc / a.st.n_chunks, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
+    if (hp_run_item<CH>(a, kc / a.st.n_chunks, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
 }
 
 // ---- elementwise stages (planar, in place) -------------------------------------------
@@ -2741,6 +2845,7 @@ struct Layout {
     bool merge;      // followers / tracker: the two recurrences of a chunk in one lane (k_*_both; saturated launches)
     bool hp_early;   // whole runs stop early at a sub-chunk boundary (k_hp_run)
     bool hp_staged;  // candidates in stages with duplicate runs removed between them (k_hp_seg*)
+    bool in_il;      // the IIR stage reads the caller's interleaved audio (no planar copy of the input is made)
     int64_t ar_L, ar_W, ar_Wc, ar_Wf, ar_chunks, ar_S;
     bool ar_sym;  // closed-form guess for the slow follower (k_ar_guess_sym)
     int64_t mm_L, mm_W, mm_chunks, mm_S;
@@ -2817,6 +2922,12 @@ Layout make_layout(const ofp_detector* d, int64_t n_clips, int64_t N, int64_t wa
         if (l.hp_W < 8192 || l.hp_R < 2) l.hp_staged = false;
         if (l.hp_staged) l.hp_span = 1;
     }
+    // The caller's interleaved audio instead of a planar copy (staged candidates, 4 or 8 channels, high-pass on: without it
+    // the dB pass reads the planar copy): only on request (tuning `interleaved` 2 / 3).  Measured, 48 C2 clips: the planar
+    // copy costs 8.9 GB per call, but a lane that walks an interleaved series issues one 4-byte load per step instead of
+    // one 16-byte load per four, and a wave's load instruction costs about as many cycles (~64) as the IIR step it feeds
+    // (~66): k_hp_seg_chunk 3.7 -> 7.9 ms, k_hp_seg 1.9 -> 5.3 ms alone, 183 -> 168 M frames/s in flight.
+    l.in_il = d->t.interleaved >= 2 && l.hp_staged && (g.C == 4 || g.C == 8) && p.hp_enabled;
     // sub-chunks: run in parallel once a chunk's start is verified (every candidate records its state at the inner
     // boundaries).  Long chunks (batches) get more of them, about 4096 samples each, and their whole runs from a
     // true start state stop at the first boundary where they have joined a candidate (k_hp_run, `early`): a break
@@ -3156,12 +3267,14 @@ const float* ofp_detect_planar_input(const ofp_detector* d, int64_t n_clips, int
                                      const void* d_ws) {
     if (!d || !d_ws || n_clips < 1 || n_samples < 0) return nullptr;
     const Layout l = make_layout(d, n_clips, n_samples, warm);
+    if (l.in_il) return nullptr;  // no planar copy in this layout: read the caller's own array
     return reinterpret_cast<const float*>(static_cast<const char*>(d_ws) + l.o_xt) + l.g.n_w;
 }
 
 int64_t ofp_detect_planar_stride(const ofp_detector* d, int64_t n_clips, int64_t n_samples, int64_t warm) {
     if (!d || n_clips < 1 || n_samples < 0) return -1;
-    return make_layout(d, n_clips, n_samples, warm).g.Nv;
+    const Layout l = make_layout(d, n_clips, n_samples, warm);
+    return l.in_il ? 0 : l.g.Nv;  // 0: no planar copy (see ofp_detect_planar_input)
 }
 
 int64_t ofp_detect_workspace_bytes(const ofp_detector* d, int64_t n_clips, int64_t n_samples,
@@ -3244,7 +3357,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const size_t tile_lds = (size_t)g.C * (l.tu + 4) * sizeof(float);
     const float* rel = dif;  // (the relative envelope overwrites the follower difference in place)
     // tracker, crossing pass and backtracking on the interleaved envelope (see k_mm_warm_il): the planar copy is not written
-    const bool mm_il = d->t.interleaved >= 0 && l.merge && d_rel != nullptr && !p.manual && (g.C == 4 || g.C == 8);
+    const bool mm_il = d->t.interleaved >= 0 && d->t.interleaved != 2 && l.merge && d_rel != nullptr && !p.manual && (g.C == 4 || g.C == 8);
     float* rel_warm = reinterpret_cast<float*>(ws + l.o_relw);
 
     // --- the last stage's arguments, needed by the completion as well (sequential machine as the fall-back)
@@ -3402,9 +3515,11 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             hipLaunchKernelGGL(k_zero, dim3((unsigned)cdiv(n16, 256)), dim3(256), 0, stream, reinterpret_cast<uint4*>(ws + l.o_zero), n16);
             OFP_LAUNCH_CHECK("k_zero");
         }
-        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
-                           stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
-        OFP_LAUNCH_CHECK("k_transpose_in");
+        if (!l.in_il) {
+            hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
+                               stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
+            OFP_LAUNCH_CHECK("k_transpose_in");
+        }
         if (timed) OFP_HIP(hipEventRecord(ev[8], stream));
     }
     if (phase == 5) return OFP_OK;
@@ -3426,7 +3541,13 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         HpCand hc;
         hc.st.g = g;
         hc.st.xt = xt;
+        hc.st.x_il = d_x;
         hc.st.out = xdb;
+        const int ch = l.in_il ? g.C : 0;
+        const auto kseg0 = ch == 8 ? k_hp_seg0<8> : (ch == 4 ? k_hp_seg0<4> : k_hp_seg0<0>);
+        const auto kseg = ch == 8 ? k_hp_seg<8> : (ch == 4 ? k_hp_seg<4> : k_hp_seg<0>);
+        const auto kseg_chunk = ch == 8 ? k_hp_seg_chunk<8> : (ch == 4 ? k_hp_seg_chunk<4> : k_hp_seg_chunk<0>);
+        const auto krun = ch == 8 ? k_hp_run<8> : (ch == 4 ? k_hp_run<4> : k_hp_run<0>);
         std::memcpy(hc.st.b, d->b, sizeof(hc.st.b));
         std::memcpy(hc.st.a, d->a, sizeof(hc.st.a));
         hc.st.L = l.hp_L;
@@ -3483,7 +3604,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             int32_t* goff = reinterpret_cast<int32_t*>(ws + l.o_hp_goff);
             int32_t* gcnt = goff + nC0;
             const unsigned full_grid = (unsigned)cdiv(n0, HP_CAND_THREADS);
-            hipLaunchKernelGGL(k_hp_seg0, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[0], goff, gcnt, cuts[0], n0);
+            hipLaunchKernelGGL(kseg0, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[0], goff, gcnt, cuts[0], n0);
             OFP_LAUNCH_CHECK("k_hp_seg0");
             int cur = 0;
             for (int m = 0; m < n_cuts; ++m) {
@@ -3492,10 +3613,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 cur ^= 1;
                 // (the grid is sized for the worst case, every run distinct; the lanes beyond the list leave at once)
                 if (m + 1 < n_cuts)
-                    hipLaunchKernelGGL(k_hp_seg, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
+                    hipLaunchKernelGGL(kseg, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
                                        (const int*)(stage_n + m), cuts[m], cuts[m + 1]);
                 else
-                    hipLaunchKernelGGL(k_hp_seg_chunk, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
+                    hipLaunchKernelGGL(kseg_chunk, dim3(full_grid), dim3(HP_CAND_THREADS), 0, stream, hc, rl[cur],
                                        (const int*)(stage_n + m));
             }
             OFP_LAUNCH_CHECK("k_hp_dedupe / k_hp_seg / k_hp_seg_chunk");
@@ -3559,7 +3680,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                 hc.prev = q > 0 ? c + 2 * (q - 1) : nullptr;
                 hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
                 hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
-                hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
+                hipLaunchKernelGGL(krun, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
             }
             OFP_LAUNCH_CHECK("k_hp_match / k_hp_resolve / k_hp_run");
             pend.hp_rounds = NR;
@@ -3582,7 +3703,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
                     hc.prev = last;
                     hipLaunchKernelGGL(k_hp_match, dim3((unsigned)cdiv(nM, 256)), dim3(256), 0, stream, hc, nM);
                     hipLaunchKernelGGL(k_hp_resolve, dim3((unsigned)chains), dim3(64), 0, stream, hc);
-                    hipLaunchKernelGGL(k_hp_run, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
+                    hipLaunchKernelGGL(krun, dim3((unsigned)cdiv(nC, 64)), dim3(64), 0, stream, hc, nC);
                     last = hc.counters;
                 }
                 OFP_LAUNCH_CHECK("k_hp_match / k_hp_resolve / k_hp_run");

@@ -160,14 +160,16 @@ class BatchDetector:
     def planar_input(self, x, warm=None):
         """(device address, stride in floats) of the planar copy of `x` (one series per clip and
         channel, `stride` floats apart) that `begin` (or `detect`) left in the work space; valid
-        until the next begin/detect on this detector."""
+        until the next begin/detect on this detector.  None when the detector's layout reads `x` itself."""
         if x.dim() == 2:
             x = x.unsqueeze(0)
         n_clips, N, C = x.shape
         warm = int(0.5 * self.sr) if warm is None else int(warm)
         ws = self.reserve(n_clips, N, warm)
-        return (self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr()),
-                int(self.d.lib.ofp_detect_planar_stride(self.d.handle, n_clips, N, warm)))
+        stride = int(self.d.lib.ofp_detect_planar_stride(self.d.handle, n_clips, N, warm))
+        if stride == 0:  # the detector works on the interleaved array itself (tuning `interleaved`): there is no planar copy
+            return None
+        return (self.d.lib.ofp_detect_planar_input(self.d.handle, n_clips, N, warm, ws.data_ptr()), stride)
 
     def _call_args(self, x, warm, want_rel, cap_per_clip, out):
         if x.dim() == 2:

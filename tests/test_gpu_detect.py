@@ -75,11 +75,18 @@ def test_c2_slice_default_tuning(det):
 ])
 def test_interleaved_layout_matches_planar_and_oracle(det, C, kw):
     """Throughput layout with 4 / 8 channels: tracker, crossing pass and backtracking read the caller's interleaved `rel`
-    (warm-up rows from a buffer of their own; walk_il's joint falls inside a chunk, and with the odd chunk length inside
-    a batch) and no planar copy is written.  == the planar layout == the oracle, bit for bit."""
+    (warm-up rows from a buffer of their own; the joint falls inside a chunk), no planar copy of it is written; on request
+    (interleaved 2 / 3) the IIR stage reads the caller's interleaved audio, no planar copy of the input.  == the planar
+    layout == the oracle, bit for bit.  (Without the high-pass -- the B = 32 case -- the input side keeps its planar
+    copy: the dB pass reads it.)"""
     x = synth.c2_drums(2.7, C, SR, seed=11 + C)[: 129_003]   # (not a whole number of blocks)
     for tuning in (dict(lane_merge=1, hp_dedupe=1), dict(lane_merge=1, mm_chunk=1999, mm_warm=5000, mm_span=3),
-                   dict(lane_merge=1, interleaved=-1)):
+                   dict(lane_merge=1, hp_dedupe=1, interleaved=3), dict(lane_merge=1, hp_dedupe=1, interleaved=2),
+                   # the IIR stage on the interleaved audio (on request) with the restart of the stream (n_w) inside a
+                   # chunk and a sub-chunk; few candidates and a short warm-up: whole re-runs and early joins
+                   dict(hp_dedupe=1, hp_chunk=3072, hp_warm=8192, hp_candidates=4, hp_early=1, interleaved=3),
+                   dict(hp_dedupe=1, hp_chunk=1001 * 4, hp_warm=9000, hp_candidate_offset=-1, interleaved=2),
+                   dict(lane_merge=1, hp_dedupe=1, interleaved=-1)):
         check_clip(det, x, tuning=tuning, **kw)
     recs, rel, info = det.detect_batch(np.stack([x, x[::-1].copy()]), tuning=dict(lane_merge=1), warm=0, **kw)
     recs2, rel2, _ = det.detect_batch(np.stack([x, x[::-1].copy()]), tuning=dict(lane_merge=1, interleaved=-1), warm=0, **kw)

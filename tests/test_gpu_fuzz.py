@@ -73,7 +73,7 @@ def random_case(rng):
     if rng.random() < 0.25:
         tuning["host_verify"] = 1   # the host-verified pass groups of rounds 1-2 (default: chain-local kernels)
     if rng.random() < 0.3:
-        tuning["interleaved"] = -1  # planar copies throughout (default: 4 / 8 channels in the merged layout read the interleaved arrays)
+        tuning["interleaved"] = int(rng.choice([-1, 2, 3]))  # planar copies throughout / the IIR stage on the interleaved audio too
     return x, kw, tuning
 
 

@@ -89,6 +89,9 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(lane_merge=1),         # fast/slow follower and min/max as one lane per chunk
                    dict(lane_merge=1, ar_chunk=2048, ar_warm=9000, mm_chunk=2048, mm_warm=6000, ar_span=4, mm_span=4),
                    dict(lane_merge=1, mm_chunk=1024, mm_warm=-1),   # no tracker warm-up: the repair passes do the work
+                   dict(lane_merge=1, interleaved=-1),   # planar copies of `rel` and the input throughout
+                   dict(lane_merge=1, hp_dedupe=1, interleaved=3),  # ... and none at all: every stage on the caller's arrays
+                   dict(hp_dedupe=1, interleaved=2, hp_chunk=8192, hp_warm=12000, hp_candidates=4),
                    dict(concurrent_calls=64),
                    None):
         bd = detection.BatchDetector(8, 256, sr=SR)
@@ -103,6 +106,29 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
             assert got[2] == len(ch) and np.array_equal(bits(got[1][0]), bits(orel))
         else:
             assert got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1]))
+
+
+def test_pipeline_without_planar_copies_gives_the_same_bytes(mods):
+    """With the detector on the caller's interleaved audio (tuning interleaved 3) there is no planar copy for the
+    spectral branch either: `planar_input` is None and the STFT takes its interleaved sliding form.  Records, `rel`,
+    |X|^2, mel and logits equal the default pipeline's, byte for byte (4 and 8 channels)."""
+    from onset_fingerprinting_amd.pipeline import FingerprintPipeline
+    for C, gen in ((8, lambda i: synth.c2_drums(4.0, 8, SR, seed=40 + i)), (4, lambda i: synth.c4_clip(i, 4.0, 4, SR))):
+        x = torch.from_numpy(np.stack([gen(i) for i in range(3)])).cuda().contiguous()
+        outs = []
+        for tuning in (dict(lane_merge=1, hp_dedupe=1), dict(lane_merge=1, hp_dedupe=1, interleaved=3)):
+            pipe = FingerprintPipeline(C, 1024, 256, SR, 40)
+            pipe.detector.set_tuning(**tuning)
+            assert (pipe.detector.planar_input(x) is None) == (tuning.get("interleaved") == 3)
+            o = pipe.run(x)
+            torch.cuda.synchronize()
+            outs.append({k: o[k].clone() for k in ("records", "counts", "rel", "power", "mel", "logits")})
+        n = outs[0]["counts"]
+        assert torch.equal(n, outs[1]["counts"]) and int(n.min()) > 20
+        for i in range(3):
+            assert torch.equal(outs[0]["records"][i, :int(n[i])], outs[1]["records"][i, :int(n[i])])
+        for k in ("rel", "power", "mel", "logits"):
+            assert torch.equal(outs[0][k], outs[1][k]), k
 
 
 def test_c2_at_full_size_matches_the_oracle_bit_for_bit(mods):

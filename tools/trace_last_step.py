@@ -1,4 +1,4 @@
-"""The kernels of the LAST step in a rocprofv3 kernel trace (from its k_transpose_in on), in launch order:
+"""The kernels of the LAST step in a rocprofv3 kernel trace (from the call's zero fill on), in launch order:
 start offset, duration, name -- what one call looks like with the GPU to itself (`bench.py --inflight 1`).
 
     python tools/trace_last_step.py <rocprof output dir>
@@ -7,7 +7,7 @@ import csv, glob, re, sys
 
 f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-t0 = [int(r["Start_Timestamp"]) for r in rows if "k_transpose_in" in r["Kernel_Name"]][-1]
+t0 = [int(r["Start_Timestamp"]) for r in rows if "k_zero(" in r["Kernel_Name"] or "k_zero<" in r["Kernel_Name"] or r["Kernel_Name"].endswith("k_zero")][-1]
 tot = {}
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
