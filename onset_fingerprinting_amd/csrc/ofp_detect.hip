@@ -1154,7 +1154,8 @@ __device__ __forceinline__ void hp_span(const HpArgs& a, F& f, int64_t chain, in
     int norem = -1;
     if constexpr (CH > 0) {
         // the caller's interleaved audio: stream position v is row v (v < n_w) or row v - n_w of the clip
-        const int64_t clip = chain / CH;
+        constexpr int CHD = CH > 0 ? CH : 1;
+        const int64_t clip = chain / CHD;
         const float* xs = a.x_il + clip * a.g.N * CH + (chain - clip * CH);
         if (!OUT) {
             if (t1 > t0) {
@@ -1362,9 +1363,10 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg0(HpCand a, HpRuns ou
     int r, c;
     int64_t grp, j, chain, clip;
     const int C = st.g.C;
+    constexpr int CHD = CH > 0 ? CH : 1;  // (divisor in the branches that are dead for CH = 0)
     if (CH > 0) {
-        c = (int)(q % CH);
-        q /= CH;
+        c = (int)(q % CHD);
+        q /= CHD;
         r = (int)(q % a.R);
         q /= a.R;
         j = q % st.n_chunks;
@@ -1459,8 +1461,9 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg(HpCand a, HpRuns run
     if (id >= *n_runs) return;
     const HpArgs& st = a.st;
     const int64_t grp = runs.grp[id];
-    const int64_t j = CH > 0 ? (grp / CH) % st.n_chunks : grp % st.n_chunks;
-    const int64_t chain = CH > 0 ? grp / (CH * st.n_chunks) * CH + grp % CH : grp / st.n_chunks;
+    constexpr int CHD = CH > 0 ? CH : 1;  // (divisor in the branch that is dead for CH = 0)
+    const int64_t j = CH > 0 ? (grp / CHD) % st.n_chunks : grp % st.n_chunks;
+    const int64_t chain = CH > 0 ? grp / (CHD * st.n_chunks) * CH + grp % CHD : grp / st.n_chunks;
     HpStep s;
     s.coeffs(st.b, st.a);
     const float4 v = runs.z[id];
@@ -1478,8 +1481,9 @@ __global__ __launch_bounds__(HP_CAND_THREADS) void k_hp_seg_chunk(HpCand a, HpRu
     const HpArgs& st = a.st;
     const int64_t grp = runs.grp[id];
     const uint32_t mask = runs.mask[id];
-    const int64_t k = CH > 0 ? (grp / CH) % st.n_chunks : grp % st.n_chunks;
-    const int64_t chain = CH > 0 ? grp / (CH * st.n_chunks) * CH + grp % CH : grp / st.n_chunks;
+    constexpr int CHD = CH > 0 ? CH : 1;  // (divisor in the branch that is dead for CH = 0)
+    const int64_t k = CH > 0 ? (grp / CHD) % st.n_chunks : grp % st.n_chunks;
+    const int64_t chain = CH > 0 ? grp / (CHD * st.n_chunks) * CH + grp % CHD : grp / st.n_chunks;
     const int C = st.g.C;
     const int64_t clip = chain / C;
     const int c = (int)(chain % C);
@@ -1865,8 +1869,9 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
     if (CH > 0) {  // lane = (clip, chunk, sub-chunk, channel): see k_hp_seg0
-        const int c = (int)(id % CH);
-        const int64_t q = id / CH;
+        constexpr int CHD = CH > 0 ? CH : 1;
+        const int c = (int)(id % CHD);
+        const int64_t q = id / CHD;
         const int sb = (int)(q % a.S);
         const int64_t kc = q / a.S;
         if (hp_run_item<CH>(a, kc / a.st.n_chunks * CH + c, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
@@ -2198,7 +2203,7 @@ template <int CH>
 __global__ __launch_bounds__(256) void k_block_scan_il(ScanArgs a, const float* __restrict__ rel_il) {
     OFP_LATENCY_BOUND_KERNEL();
     constexpr int RPS = 64 / CH;  // rows per step
-    constexpr unsigned long long CHM = CH == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    constexpr unsigned long long CHM = CH == 8 ? 0x0101010101010101ull : (CH == 4 ? 0x1111111111111111ull : 1ull);  // (CH = 64: one row per step)
     const int B = a.g.B;
     const int lane = threadIdx.x & 63;
     const int c = lane % CH, rl = lane / CH;
@@ -3357,7 +3362,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     const size_t tile_lds = (size_t)g.C * (l.tu + 4) * sizeof(float);
     const float* rel = dif;  // (the relative envelope overwrites the follower difference in place)
     // tracker, crossing pass and backtracking on the interleaved envelope (see k_mm_warm_il): the planar copy is not written
-    const bool mm_il = d->t.interleaved >= 0 && d->t.interleaved != 2 && l.merge && d_rel != nullptr && !p.manual && (g.C == 4 || g.C == 8);
+    const bool mm_il = d->t.interleaved >= 0 && d->t.interleaved != 2 && l.merge && d_rel != nullptr && !p.manual &&
+                       (g.C == 4 || g.C == 8 || g.C == 64);
     float* rel_warm = reinterpret_cast<float*>(ws + l.o_relw);
 
     // --- the last stage's arguments, needed by the completion as well (sequential machine as the fall-back)
@@ -3846,6 +3852,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
             if (mm_il && g.C == 8)
                 hipLaunchKernelGGL(k_mm_warm_il<8>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+            else if (mm_il && g.C == 64)
+                hipLaunchKernelGGL(k_mm_warm_il<64>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             else if (mm_il)
                 hipLaunchKernelGGL(k_mm_warm_il<4>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             else if (l.merge)
@@ -3865,11 +3873,14 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             const int64_t n = m.n_chains * m.n_chunks;
             if (m.g.C == 8)
                 hipLaunchKernelGGL(k_mm_maxpass_il<8>, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
+            else if (m.g.C == 64)
+                hipLaunchKernelGGL(k_mm_maxpass_il<64>, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
             else
                 hipLaunchKernelGGL(k_mm_maxpass_il<4>, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, m, n, ep, en, u, ch, gate);
         };
         const MmLight light = mm_il ? light_il : light_pl;
-        const auto mm_chunk_k = mm_il ? (g.C == 8 ? k_mm_chunk_il<8> : k_mm_chunk_il<4>) : (l.merge ? k_mm_chunk_both : k_mm_chunk);
+        const auto mm_chunk_k = mm_il ? (g.C == 8 ? k_mm_chunk_il<8> : (g.C == 64 ? k_mm_chunk_il<64> : k_mm_chunk_il<4>))
+                                      : (l.merge ? k_mm_chunk_both : k_mm_chunk);
         if (!hv_fm) {
             pend.mm_nv = l.mm_chunks > 1 ? std::max(2, std::min(AHEAD_MAX_PASSES / 2, d->mm_pass_hint)) : 0;
             if (int rc = run_jacobi_ahead("tracker stage", mm_chunk_k, a,
@@ -3910,6 +3921,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             const unsigned il_grid = (unsigned)std::min<int64_t>(cdiv(n_clips * l.nb, 4), 256 * 32);
             if (g.C == 8)
                 hipLaunchKernelGGL(k_block_scan_il<8>, dim3(il_grid), dim3(256), 0, stream, sa, d_rel);
+            else if (g.C == 64)
+                hipLaunchKernelGGL(k_block_scan_il<64>, dim3(il_grid), dim3(256), 0, stream, sa, d_rel);
             else
                 hipLaunchKernelGGL(k_block_scan_il<4>, dim3(il_grid), dim3(256), 0, stream, sa, d_rel);
         } else {

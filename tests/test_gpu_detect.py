@@ -66,7 +66,7 @@ def test_c2_slice_default_tuning(det):
     assert np.array_equal(np.array(c), g["c2_ch"]) and np.array_equal(np.array(o), g["c2_on"])
 
 
-@pytest.mark.parametrize("C", [4, 8])
+@pytest.mark.parametrize("C", [4, 8, 64])
 @pytest.mark.parametrize("kw", [
     dict(block_size=256, sr=SR),
     dict(block_size=100, sr=SR, cooldown=20),                       # rows per block not a power of two, not a multiple of 64 / C
@@ -74,7 +74,7 @@ def test_c2_slice_default_tuning(det):
     dict(block_size=256, sr=SR, backtrack=True, backtrack_buffer_size=512, backtrack_smooth_size=5),
 ])
 def test_interleaved_layout_matches_planar_and_oracle(det, C, kw):
-    """Throughput layout with 4 / 8 channels: tracker, crossing pass and backtracking read the caller's interleaved `rel`
+    """Throughput layout with 4 / 8 / 64 channels: tracker, crossing pass and backtracking read the caller's interleaved `rel`
     (warm-up rows from a buffer of their own; the joint falls inside a chunk), no planar copy of it is written; on request
     (interleaved 2 / 3) the IIR stage reads the caller's interleaved audio, no planar copy of the input.  == the planar
     layout == the oracle, bit for bit.  (Without the high-pass -- the B = 32 case -- the input side keeps its planar
