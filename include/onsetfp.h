@@ -159,6 +159,12 @@ typedef struct ofp_detect_tuning {
                                     the audio as it is, no planar copy of the input is made -- slower (one 4-byte load per
                                     step and lane), kept for measurement.  0 auto (the `rel` side whenever its conditions
                                     hold), < 0 never, 1 the `rel` side, 2 the input side, 3 both.  Results do not change. */
+    int64_t walk_through;        /* throughput layout: the chunks a speculative warm-up run walks through after its warm-up
+                                    (all but the last of every group of `span` chunks) count as their pass 0 -- the run
+                                    leaves their outputs and end states, the chunk pass runs the others only: one pass
+                                    over the stream less for those chunks (followers: the merged layout with the
+                                    closed-form guess; tracker: on the interleaved envelope).  0 on, < 0 off.  Results
+                                    do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -66,6 +66,7 @@ class DetectTuning(ctypes.Structure):
         ("scan_skip", ctypes.c_int64),
         ("host_verify", ctypes.c_int64),
         ("interleaved", ctypes.c_int64),
+        ("walk_through", ctypes.c_int64),
     ]
 
 

@@ -518,7 +518,13 @@ struct ArArgs {
     float fa, fr, sa, sr, floor_db;
     int64_t L, W, Wc, Wf, n_chunks;
     int64_t S;  // span of k_ar_warm2: chunks one speculative run walks through after its warm-up
+    int through;  // k_ar_warm_both wrote the differences and the end states of the chunks it walked through (all but the
+                  // last of every group of S): pass 0 of k_ar_chunk runs the others only
 };
+// chunk k was walked through by its group's speculative run (ArArgs::through, MmArgs::through)
+__device__ __forceinline__ bool chunk_walked(int64_t k, int64_t S, int64_t n_chunks) {
+    return k + 1 < min((k / S) * S + S, n_chunks);
+}
 
 // The stage is split into LEAN kernels, one walk instantiation each: measured on gfx950, the
 // very same loop runs 3-4x slower inside a kernel that also carries the other (heavily
@@ -691,7 +697,11 @@ __global__ __launch_bounds__(64) void k_ar_warm2(ArArgs a, int64_t n_threads, ui
 // length of a lane's dependent chain, and the two lanes of a chunk read the same samples at different times (the
 // slow one W ahead of the chunk, the fast one Wf), so each line of the stream came from HBM twice.  Here the
 // fast follower simply starts with the slow one (a longer warm-up than it needs).
-__global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+__global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used,
+                                                     uint32_t* __restrict__ end0) {
+    // a.through: the chunks the run walks through after its warm-up ARE their pass 0 -- it writes their differences and
+    // their end states (end0 = the end array pass 0 writes) exactly as k_ar_chunk would from the same start state: one
+    // pass over the dB stream less for those chunks.  (A wrong start guess is repaired by the verifying passes as before.)
     OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
@@ -708,10 +718,16 @@ __global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads
     walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
     used[s0] = ofp_f2u(s.yf);
     used[s0 + 1] = ofp_f2u(s.ys);
+    float* os = a.dif + chain * a.g.U;
     for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
-        walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
+        if (a.through) walk<8, 4, false>(xs + (k - 1) * a.L, os + (k - 1) * a.L, a.L, norem, s);
+        else walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
         used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.yf);
         used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.ys);
+        if (a.through) {
+            end0[(chain * a.n_chunks + k - 1) * 2] = ofp_f2u(s.yf);
+            end0[(chain * a.n_chunks + k - 1) * 2 + 1] = ofp_f2u(s.ys);
+        }
     }
 }
 
@@ -730,6 +746,7 @@ __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_t
     const int64_t start = k * a.L;
     const int64_t end = min(start + a.L, a.g.U);
     const int64_t sidx = (chain * a.n_chunks + k) * 2;
+    if (pass == 0 && a.through && chunk_walked(k, a.S, a.n_chunks)) return;  // k_ar_warm_both has been through it
     uint32_t i0 = used[sidx], i1 = used[sidx + 1];
     if (pass > 0) {
         if (k == 0) {
@@ -770,8 +787,9 @@ struct MmArgs {
     uint8_t* dirty;  // [chains][n_chunks] chunk must be run again although its start matches (k_mm_sweep)
     int64_t n_chains;
     int64_t S;  // span of k_mm_warm2: chunks one speculative run walks through after its warm-up
+    int through;  // k_mm_warm_il left the per-block outputs and the end states of the chunks it walked through (all but
+                  // the last of every group of S): pass 0 of k_mm_chunk_il runs the others only
 };
-
 // The min and the max are two independent recurrences and are treated as such: every launch of
 // this stage has one lane per (chain, chunk) for the max (first half of the grid) and one for the
 // min (second half), each walking a one-word step (11-15 ns instead of 25-35 ns for the pair).
@@ -1020,7 +1038,12 @@ __device__ __forceinline__ IlSrc mm_il_range(const MmArgs& a, int64_t clip, int 
 }
 
 template <int CH>
-__global__ __launch_bounds__(64) void k_mm_warm_il(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used) {
+__global__ __launch_bounds__(64) void k_mm_warm_il(MmArgs a, int64_t n_threads, uint32_t* __restrict__ used,
+                                                   uint32_t* __restrict__ end0) {
+    // a.through: the chunks the run walks through after its warm-up ARE their pass 0 -- the run stores the tracker state
+    // at their block ends and their end states (end0 = the end array pass 0 writes), exactly as k_mm_chunk_il would from
+    // the same start state; one pass over the stream less.  A start guess that turns out wrong is repaired by the
+    // verifying passes as before (they compare used[k] with the end of chunk k - 1, whoever wrote it).
     OFP_LATENCY_BOUND_KERNEL();
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_threads) return;
@@ -1032,19 +1055,36 @@ __global__ __launch_bounds__(64) void k_mm_warm_il(MmArgs a, int64_t n_threads, 
     const int64_t chain = clip * CH + c;
     const int64_t k0 = g * a.S;
     const int64_t start = k0 * a.L;
-    int norem = -1;
+    int rem = -1;  // (no events during the warm-up)
     const int64_t ws = max<int64_t>(start - a.W, 0);
     MmStep s{ws > 0 ? __builtin_inff() : a.min0, ws > 0 ? 0.0f : a.max0, a.minmin, v2f{a.ialpha_min, a.ialpha_max},
-             v2f{a.alpha_min, a.alpha_max}, nullptr, nullptr, 0, 0, nullptr};
+             v2f{a.alpha_min, a.alpha_max}, nullptr, nullptr, CH, a.g.B, &rem};
     IlSrc q = mm_il_range(a, clip, c, ws, start);
-    walk_il2<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+    walk_il2<CH, 32, true>(q.p0, q.n0, q.p1, q.n1, rem, s);
     used[(chain * a.n_chunks + k0) * 2] = ofp_f2u(s.mn);
     used[(chain * a.n_chunks + k0) * 2 + 1] = ofp_f2u(s.mx);
+    if (a.through) {  // block-end output from chunk k0 on (as in k_mm_chunk_il)
+        const int64_t m = start - a.g.n_wb;
+        int64_t j = 0;
+        if (m >= 0) {
+            j = m / a.g.B;
+            rem = (int)(a.g.B - 1 - (m - j * a.g.B));
+        } else {
+            rem = (int)min<int64_t>(-m + a.g.B - 1, 0x7fffffff);
+        }
+        const int64_t oi = (clip * a.nb + j) * CH + c;
+        s.pmn = a.thr_mn + oi;
+        s.pmx = a.thr_mx + oi;
+    }
     for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
         q = mm_il_range(a, clip, c, (k - 1) * a.L, k * a.L);
-        walk_il2<CH, 32, false>(q.p0, q.n0, q.p1, q.n1, norem, s);
+        walk_il2<CH, 32, true>(q.p0, q.n0, q.p1, q.n1, rem, s);
         used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.mn);
         used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.mx);
+        if (a.through) {
+            end0[(chain * a.n_chunks + k - 1) * 2] = ofp_f2u(s.mn);
+            end0[(chain * a.n_chunks + k - 1) * 2 + 1] = ofp_f2u(s.mx);
+        }
     }
 }
 
@@ -1066,6 +1106,7 @@ __global__ __launch_bounds__(64) void k_mm_chunk_il(MmArgs a, int pass, int64_t 
     const int64_t start = k * a.L;
     const int64_t end = min(start + a.L, a.g.U);
     const int64_t sidx = did * 2;
+    if (pass == 0 && a.through && chunk_walked(k, a.S, a.n_chunks)) return;  // k_mm_warm_il has been through it
     uint32_t i0 = used[sidx], i1 = used[sidx + 1];
     if (pass > 0) {
         if (k == 0) {
@@ -3751,6 +3792,9 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     a.Wf = l.ar_Wf;
     a.n_chunks = l.ar_chunks;
     a.S = l.ar_S;
+    {   // walk-through chunks as their own pass 0 (k_ar_warm_both): the merged layout with 16-byte-congruent buffers
+        a.through = (d->t.walk_through >= 0 && l.merge && l.ar_sym && (g.U & 3) == 0 && (l.ar_L & 3) == 0) ? 1 : 0;
+    }
     // dB and the per-chunk sums of the closed-form guess in one pass whenever both are wanted and the geometry
     // allows 16-byte groups (otherwise k_rect_db, then k_ar_sym_local reading the dB stream once more)
     const bool db_sym = l.ar_sym && p.hp_enabled && (g.U & 3) == 0 && (l.ar_L & 3) == 0 && d->t.fuse_db_sums >= 0;
@@ -3788,7 +3832,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (l.ar_sym) {
             const int64_t ntg = chains * cdiv(l.ar_chunks, l.ar_S);  // one run per group of S chunks
             if (l.merge)
-                hipLaunchKernelGGL(k_ar_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+                hipLaunchKernelGGL(k_ar_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used, used + 2 * nt);
             else
                 hipLaunchKernelGGL(k_ar_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_ar_warm2");
@@ -3845,17 +3889,18 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         a.n_chunks = l.mm_chunks;
         a.n_chains = chains;
         a.S = l.mm_S;
+        a.through = (mm_il && d->t.walk_through >= 0) ? 1 : 0;
         a.dirty = reinterpret_cast<uint8_t*>(ws + l.o_mm_dirty);
         const int64_t nt = chains * l.mm_chunks;
         uint32_t* used = reinterpret_cast<uint32_t*>(ws + l.o_mm_state);
         {
             const int64_t ntg = chains * cdiv(l.mm_chunks, l.mm_S);  // one run per group of S chunks
             if (mm_il && g.C == 8)
-                hipLaunchKernelGGL(k_mm_warm_il<8>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+                hipLaunchKernelGGL(k_mm_warm_il<8>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used, used + 2 * nt);
             else if (mm_il && g.C == 64)
-                hipLaunchKernelGGL(k_mm_warm_il<64>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+                hipLaunchKernelGGL(k_mm_warm_il<64>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used, used + 2 * nt);
             else if (mm_il)
-                hipLaunchKernelGGL(k_mm_warm_il<4>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
+                hipLaunchKernelGGL(k_mm_warm_il<4>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used, used + 2 * nt);
             else if (l.merge)
                 hipLaunchKernelGGL(k_mm_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             else

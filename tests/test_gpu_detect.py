@@ -86,6 +86,11 @@ def test_interleaved_layout_matches_planar_and_oracle(det, C, kw):
                    # chunk and a sub-chunk; few candidates and a short warm-up: whole re-runs and early joins
                    dict(hp_dedupe=1, hp_chunk=3072, hp_warm=8192, hp_candidates=4, hp_early=1, interleaved=3),
                    dict(hp_dedupe=1, hp_chunk=1001 * 4, hp_warm=9000, hp_candidate_offset=-1, interleaved=2),
+                   dict(lane_merge=1, hp_dedupe=1, walk_through=-1),
+                   # walk-through chunks as their own pass 0, with spans and chunk lengths that put group ends, the joint
+                   # of the two `rel` pieces and the stream's end in every position; no warm-up: the repairs run through them
+                   dict(lane_merge=1, ar_chunk=2048, ar_span=4, mm_chunk=2048, mm_span=5, mm_warm=3000),
+                   dict(lane_merge=1, ar_chunk=4096, ar_warm=-1, ar_span=8, mm_chunk=1024, mm_warm=-1, mm_span=16),
                    dict(lane_merge=1, hp_dedupe=1, interleaved=-1)):
         check_clip(det, x, tuning=tuning, **kw)
     recs, rel, info = det.detect_batch(np.stack([x, x[::-1].copy()]), tuning=dict(lane_merge=1), warm=0, **kw)

@@ -74,6 +74,8 @@ def random_case(rng):
         tuning["host_verify"] = 1   # the host-verified pass groups of rounds 1-2 (default: chain-local kernels)
     if rng.random() < 0.3:
         tuning["interleaved"] = int(rng.choice([-1, 2, 3]))  # planar copies throughout / the IIR stage on the interleaved audio too
+    if rng.random() < 0.3:
+        tuning["walk_through"] = -1  # every chunk through the chunk pass (default: walk-through chunks are their own pass 0)
     return x, kw, tuning
 
 
