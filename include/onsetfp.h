@@ -165,6 +165,11 @@ typedef struct ofp_detect_tuning {
                                     over the stream less for those chunks (followers: the merged layout with the
                                     closed-form guess; tracker: on the interleaved envelope).  0 on, < 0 off.  Results
                                     do not change. */
+    int64_t line_stores;         /* throughput layout (lane_merge), everything a multiple of 32 steps: the output walks of
+                                    the IIR stage and the followers hand every batch of 32 outputs over through LDS and
+                                    the wave stores complete 128-byte lines (8 lanes x 16 B) instead of 64 lane-private
+                                    16-byte pieces per instruction: +11 % frames/s in flight, slower for a lone call.
+                                    0 on, < 0 off.  Results do not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

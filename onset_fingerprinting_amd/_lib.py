@@ -67,6 +67,7 @@ class DetectTuning(ctypes.Structure):
         ("host_verify", ctypes.c_int64),
         ("interleaved", ctypes.c_int64),
         ("walk_through", ctypes.c_int64),
+        ("line_stores", ctypes.c_int64),
     ]
 
 

@@ -176,6 +176,74 @@ __device__ __forceinline__ void walk(const float* ip, float* op, int64_t n, int&
 }
 
 // ---------------------------------------------------------------------------
+// walk_lines: walk<8, 4, false> for a WHOLE WAVE whose stores leave as complete 128-byte lines.  A lane's own 16-byte
+// stores make every store instruction of the wave touch 64 different lines (16 B each; the lane completes its line with
+// eight instructions): measured (tools/probes/storeprobe.hip, IIR-like step, one wave per SIMD) a walker that reads
+// and writes its stream that way moves 2.5-2.9 TB/s, one whose wave hands each batch over through LDS and stores
+// 8 complete lines per instruction (8 lanes x 16 B a line) 4.7-5.0 TB/s.  All 64 lanes of the wave call this together
+// (their n may differ, 0 = nothing to do; each a multiple of 32 steps; ip / op 16-byte aligned); tile: 64 x WL_PITCH
+// floats of LDS owned by the wave.
+constexpr int WL_PITCH = 36;  // 32 + 4 floats: 16-byte rows, banks spread
+template <class F, class D>
+__device__ __forceinline__ void walk_lines_to(const float* ip, int64_t n, F& f, float* tile, D&& dst_of) {
+    // dst_of(b): where the lane's batch b (32 steps) goes, or NULL for a batch without output
+    const int lane = threadIdx.x & 63;
+    const int64_t nb = n >> 5;
+    int64_t nbmax = nb;
+    for (int o = 32; o > 0; o >>= 1) nbmax = max(nbmax, __shfl_xor(nbmax, o));
+    const float4* q = reinterpret_cast<const float4*>(ip);
+    float4 A[8], Bv[8];
+    auto load = [&](float4 (&v)[8], int64_t b) {
+        if (b < nb) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = q[i];
+            q += 8;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run = [&](const float4 (&v)[8], int64_t b) {
+        const bool have = b < nb;
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float4 o;
+                o.x = f(v[i].x); o.y = f(v[i].y); o.z = f(v[i].z); o.w = f(v[i].w);
+                *reinterpret_cast<float4*>(&tile[lane * WL_PITCH + 4 * i]) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float* const mine = have ? dst_of(b) : nullptr;
+        const unsigned long long hv = __ballot(mine != nullptr);
+        const int64_t my = reinterpret_cast<int64_t>(mine);
+        // store j: the lines of lanes 8 j .. 8 j + 7; this lane writes piece lane & 7 of lane 8 j + (lane >> 3)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int owner = 8 * j + (lane >> 3);
+            const int lo = __shfl((int)my, owner), hi = __shfl((int)(my >> 32), owner);
+            if ((hv >> owner) & 1ull) {
+                float* dst = reinterpret_cast<float*>(((int64_t)hi << 32) | (uint32_t)lo) + 4 * (lane & 7);
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&tile[owner * WL_PITCH + 4 * (lane & 7)]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (the tile is free for the next batch)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load(A, 0);
+    int64_t b = 0;
+    for (; b + 1 < nbmax; b += 2) {
+        load(Bv, b + 1); run(A, b);
+        load(A, b + 2); run(Bv, b + 1);
+    }
+    if (b < nbmax) run(A, b);
+}
+template <class F>
+__device__ __forceinline__ void walk_lines(const float* ip, float* op, int64_t n, F& f, float* tile) {
+    walk_lines_to(ip, n, f, tile, [op](int64_t b) { return op + 32 * b; });
+}
+
+// ---------------------------------------------------------------------------
 // walk_il: the same inner loop over an INTERLEAVED series ([time][channel] rows -- the caller's audio or `rel` output): a
 // lane's samples are CH floats apart and the lanes of a row's channels are neighbours, so a wave's 4-byte load covers
 // whole rows (CH = 8: eight 32-byte rows of eight chunks).  No output; EV as in walk().  CH is a template parameter so
@@ -518,6 +586,8 @@ struct ArArgs {
     float fa, fr, sa, sr, floor_db;
     int64_t L, W, Wc, Wf, n_chunks;
     int64_t S;  // span of k_ar_warm2: chunks one speculative run walks through after its warm-up
+    int lines;    // the output walks of k_ar_chunk / k_ar_warm_both store complete lines (walk_lines: everything a multiple
+                  // of 32 steps, the host checks)
     int through;  // k_ar_warm_both wrote the differences and the end states of the chunks it walked through (all but the
                   // last of every group of S): pass 0 of k_ar_chunk runs the others only
 };
@@ -697,28 +767,48 @@ __global__ __launch_bounds__(64) void k_ar_warm2(ArArgs a, int64_t n_threads, ui
 // length of a lane's dependent chain, and the two lanes of a chunk read the same samples at different times (the
 // slow one W ahead of the chunk, the fast one Wf), so each line of the stream came from HBM twice.  Here the
 // fast follower simply starts with the slow one (a longer warm-up than it needs).
+template <bool LINES>
 __global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads, uint32_t* __restrict__ used,
                                                      uint32_t* __restrict__ end0) {
     // a.through: the chunks the run walks through after its warm-up ARE their pass 0 -- it writes their differences and
     // their end states (end0 = the end array pass 0 writes) exactly as k_ar_chunk would from the same start state: one
     // pass over the dB stream less for those chunks.  (A wrong start guess is repaired by the verifying passes as before.)
+    // LINES (with a.through): those outputs leave as complete lines (walk_lines: the whole wave stays together).
     OFP_LATENCY_BOUND_KERNEL();
+    __shared__ float tile[LINES ? 64 * WL_PITCH : 1];
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;
+    const bool live = id < n_threads;
+    if (!LINES && !live) return;
     const int64_t n_groups = cdiv(a.n_chunks, a.S);
-    const int64_t g = id % n_groups;
-    const int64_t chain = id / n_groups;
+    const int64_t g = live ? id % n_groups : 0;
+    const int64_t chain = live ? id / n_groups : 0;
     const int64_t k0 = g * a.S;
     const int64_t start = k0 * a.L;
     const float* xs = a.xdb + chain * a.g.U;
     int norem = -1;
     const int64_t ws = max<int64_t>(start - a.W, 0);
     const int64_t s0 = (chain * a.n_chunks + k0) * 2;
-    ArStep s{a.floor_db, ofp_u2f(used[s0 + 1]), a.fa, a.fr, a.sa, a.sr};  // floor / closed-form guess at the run's start
-    walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
-    used[s0] = ofp_f2u(s.yf);
-    used[s0 + 1] = ofp_f2u(s.ys);
+    ArStep s{a.floor_db, live ? ofp_u2f(used[s0 + 1]) : 0.0f, a.fa, a.fr, a.sa, a.sr};  // floor / closed-form guess at the run's start
+    if (live) {
+        walk<8, 0, false>(xs + ws, nullptr, start - ws, norem, s);
+        used[s0] = ofp_f2u(s.yf);
+        used[s0 + 1] = ofp_f2u(s.ys);
+    }
     float* os = a.dif + chain * a.g.U;
+    if (LINES) {
+        for (int64_t i = 1; i < a.S; ++i) {  // (the same trip count for the whole wave)
+            const int64_t k = k0 + i;
+            const bool on = live && k < a.n_chunks;
+            walk_lines(xs + (on ? (k - 1) * a.L : 0), os + (on ? (k - 1) * a.L : 0), on ? a.L : 0, s, tile);
+            if (on) {
+                used[(chain * a.n_chunks + k) * 2] = ofp_f2u(s.yf);
+                used[(chain * a.n_chunks + k) * 2 + 1] = ofp_f2u(s.ys);
+                end0[(chain * a.n_chunks + k - 1) * 2] = ofp_f2u(s.yf);
+                end0[(chain * a.n_chunks + k - 1) * 2 + 1] = ofp_f2u(s.ys);
+            }
+        }
+        return;
+    }
     for (int64_t k = k0 + 1; k < min(k0 + a.S, a.n_chunks); ++k) {
         if (a.through) walk<8, 4, false>(xs + (k - 1) * a.L, os + (k - 1) * a.L, a.L, norem, s);
         else walk<8, 0, false>(xs + (k - 1) * a.L, nullptr, a.L, norem, s);
@@ -731,6 +821,7 @@ __global__ __launch_bounds__(64) void k_ar_warm_both(ArArgs a, int64_t n_threads
     }
 }
 
+template <bool LINES>
 __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_threads,
                                                  const uint32_t* __restrict__ end_prev,
                                                  uint32_t* __restrict__ end_next, uint32_t* __restrict__ used,
@@ -739,38 +830,53 @@ __global__ __launch_bounds__(64) void k_ar_chunk(ArArgs a, int pass, int64_t n_t
     // gate: the change counter of the pass this one follows (passes enqueued ahead of the host's knowledge): zero =
     // that pass repaired nothing, so it left both end arrays identical and this pass has nothing to do
     if (gate && *gate == 0) return;
+    __shared__ float tile[LINES ? 64 * WL_PITCH : 1];
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_threads) return;
-    const int64_t k = id % a.n_chunks;
-    const int64_t chain = id / a.n_chunks;
+    bool act = id < n_threads;
+    const int64_t k = act ? id % a.n_chunks : 0;
+    const int64_t chain = act ? id / a.n_chunks : 0;
     const int64_t start = k * a.L;
     const int64_t end = min(start + a.L, a.g.U);
     const int64_t sidx = (chain * a.n_chunks + k) * 2;
-    if (pass == 0 && a.through && chunk_walked(k, a.S, a.n_chunks)) return;  // k_ar_warm_both has been through it
-    uint32_t i0 = used[sidx], i1 = used[sidx + 1];
-    if (pass > 0) {
-        if (k == 0) {
-            end_next[sidx] = end_prev[sidx];
-            end_next[sidx + 1] = end_prev[sidx + 1];
-            return;
+    if (act && pass == 0 && a.through && chunk_walked(k, a.S, a.n_chunks)) act = false;  // k_ar_warm_both has been through it
+    uint32_t i0 = 0, i1 = 0;
+    if (act) {
+        i0 = used[sidx];
+        i1 = used[sidx + 1];
+        if (pass > 0) {
+            if (k == 0) {
+                end_next[sidx] = end_prev[sidx];
+                end_next[sidx + 1] = end_prev[sidx + 1];
+                act = false;
+            } else {
+                const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
+                if (p0 == i0 && p1 == i1) {
+                    end_next[sidx] = end_prev[sidx];
+                    end_next[sidx + 1] = end_prev[sidx + 1];
+                    act = false;
+                } else {
+                    i0 = p0;
+                    i1 = p1;
+                    used[sidx] = i0;
+                    used[sidx + 1] = i1;
+                    atomicAdd(changed, 1);
+                }
+            }
         }
-        const uint32_t p0 = end_prev[sidx - 2], p1 = end_prev[sidx - 1];
-        if (p0 == i0 && p1 == i1) {
-            end_next[sidx] = end_prev[sidx];
-            end_next[sidx + 1] = end_prev[sidx + 1];
-            return;
-        }
-        i0 = p0;
-        i1 = p1;
-        used[sidx] = i0;
-        used[sidx + 1] = i1;
-        atomicAdd(changed, 1);
     }
     ArStep s{ofp_u2f(i0), ofp_u2f(i1), a.fa, a.fr, a.sa, a.sr};
-    int norem = -1;
-    walk<8, 4, false>(a.xdb + chain * a.g.U + start, a.dif + chain * a.g.U + start, end - start, norem, s);
-    end_next[sidx] = ofp_f2u(s.yf);
-    end_next[sidx + 1] = ofp_f2u(s.ys);
+    if (LINES) {  // the whole wave stays together (walk_lines); lanes with nothing to do lend their stores
+        if (!__any(act)) return;
+        walk_lines(a.xdb + chain * a.g.U + start, a.dif + chain * a.g.U + start, act ? end - start : 0, s, tile);
+    } else {
+        if (!act) return;
+        int norem = -1;
+        walk<8, 4, false>(a.xdb + chain * a.g.U + start, a.dif + chain * a.g.U + start, end - start, norem, s);
+    }
+    if (act) {
+        end_next[sidx] = ofp_f2u(s.yf);
+        end_next[sidx + 1] = ofp_f2u(s.ys);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1921,6 +2027,112 @@ __global__ __launch_bounds__(64) void k_hp_run(HpCand a, int64_t n_threads) {
     const int sb = (int)(id % a.S);
     const int64_t kc = id / a.S;
     if (hp_run_item<CH>(a, kc / a.st.n_chunks, kc % a.st.n_chunks, sb)) atomicAdd(a.counters + 1, 1);
+}
+
+// k_hp_run whose output leaves as complete lines (walk_lines; planar input; every position that matters a multiple of 32
+// steps: the host checks).  The items' logic is hp_run_item's, arranged so that the wave stays together: every lane goes
+// through the same number of piece trips, the lanes without work (or done with theirs) lend their stores.
+__global__ __launch_bounds__(64) void k_hp_run_lines(HpCand a, int64_t n_threads) {
+    OFP_LATENCY_BOUND_KERNEL();
+    if (a.prev && a.prev[0] + a.prev[1] == 0) return;
+    __shared__ float tile[64 * WL_PITCH];
+    const HpArgs& st = a.st;
+    const int C = st.g.C;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = id < n_threads;
+    const int sb = act ? (int)(id % a.S) : 0;
+    const int64_t kc = act ? id / a.S : 0;
+    const int64_t chain = kc / st.n_chunks, k = kc % st.n_chunks;
+    const int64_t clip = chain / C;
+    const int c = (int)(chain % C);
+    const int64_t ci = (clip * st.n_chunks + k) * C + c;
+    int mg = -1, sp = 0, own = -1;
+    bool whole = false;
+    if (act) {  // (hp_run_item's conditions, in its order)
+        mg = a.mrg[ci];
+        __threadfence();
+        if (a.done[ci * a.S + sb]) act = false;
+    }
+    if (act && k > 0) {
+        sp = a.sel[ci - C];
+        if (sp < 0) act = false;  // predecessor not resolved yet
+    }
+    if (act) {
+        own = a.sel[ci];
+        whole = (own < 0 || own >= a.R || a.guessed[ci]) && mg < 0;  // no exact inner states
+        if (whole && sb > 0) act = false;
+    }
+    if (!__any(act)) return;
+    HpStep s;
+    s.coeffs(st.b, st.a);
+    uint32_t xin[4] = {0u, 0u, 0u, 0u};
+    if (act) {
+        if (sb > 0) {
+            const uint32_t* m = a.M + a.mslot(clip, k, c, mg >= 0 ? mg : own, sb - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xin[i] = m[i];
+        } else if (k > 0) {
+            const uint32_t* e = a.E + a.slot(clip, k - 1, c, sp);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xin[i] = e[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.z[i] = ofp_u2f(xin[i]);
+    const int64_t start = k * st.L;
+    const int64_t end = min(start + st.L, st.g.V);
+    const int64_t Ls = st.L / a.S;
+    const bool pieces = !whole || a.early;
+    const int q0 = whole ? 0 : sb, q1 = !whole ? sb + 1 : (a.early ? a.S : 1);
+    int joined = -1, n_done = a.S;
+    int trips = act ? q1 - q0 : 0;
+    for (int o = 32; o > 0; o >>= 1) trips = max(trips, __shfl_xor(trips, o));
+    const float* xs = st.xt + chain * st.g.Nv;
+    float* os = st.out + chain * st.g.U;
+    const Geom g = st.g;
+    for (int it = 0; it < trips; ++it) {
+        const int q = q0 + it;
+        const bool on = act && q < q1 && joined < 0;
+        const int64_t t0 = on ? (pieces ? min(start + q * Ls, end) : start) : 0;
+        const int64_t t1 = on ? ((!pieces || q == a.S - 1) ? end : min(start + (q + 1) * Ls, end)) : 0;
+        walk_lines_to(xs + t0, t1 - t0, s, tile, [&](int64_t b) -> float* {
+            const int64_t u = hp_dst(g, t0 + 32 * b);  // (a batch lies inside one of the three regions of the stream)
+            return u >= 0 ? os + u : nullptr;
+        });
+        if (on && whole && q + 1 < q1) {
+            const uint32_t z0 = ofp_f2u(s.z[0]), z1 = ofp_f2u(s.z[1]), z2 = ofp_f2u(s.z[2]), z3 = ofp_f2u(s.z[3]);
+            for (int r = 0; r < a.R; ++r) {
+                if (a.U[a.slot(clip, k, c, r)] == 0x7fc00001u) continue;  // a slot no run filled: no records
+                const uint32_t* m = a.M + a.mslot(clip, k, c, r, q);
+                if (m[0] == z0 && m[1] == z1 && m[2] == z2 && m[3] == z3) {
+                    joined = r;
+                    break;
+                }
+            }
+            if (joined >= 0) n_done = q + 1;
+        }
+    }
+    if (!act) return;
+    if (!whole) {
+        if (sb == 0) a.ran[ci] = (int8_t)own;
+        a.done[ci * a.S + sb] = 1;
+        return;
+    }
+    if (own < 0 || a.guessed[ci]) {  // (see hp_run_item)
+        uint32_t* u = a.U + a.slot(clip, k, c, a.R);
+        uint32_t* e = a.E + a.slot(clip, k, c, a.R);
+        const uint32_t* ej = joined >= 0 ? a.E + a.slot(clip, k, c, joined) : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i] = xin[i];
+            e[i] = ej ? ej[i] : ofp_f2u(s.z[i]);
+        }
+    }
+    a.ran[ci] = (int8_t)a.R;
+    for (int q = 0; q < n_done; ++q) a.done[ci * a.S + q] = 1;
+    __threadfence();
+    a.mrg[ci] = (int8_t)joined;
+    if (joined >= 0) atomicAdd(a.counters + 1, 1);  // open sub-chunks: another round
 }
 
 // ---- elementwise stages (planar, in place) -------------------------------------------
@@ -3594,7 +3806,12 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const auto kseg0 = ch == 8 ? k_hp_seg0<8> : (ch == 4 ? k_hp_seg0<4> : k_hp_seg0<0>);
         const auto kseg = ch == 8 ? k_hp_seg<8> : (ch == 4 ? k_hp_seg<4> : k_hp_seg<0>);
         const auto kseg_chunk = ch == 8 ? k_hp_seg_chunk<8> : (ch == 4 ? k_hp_seg_chunk<4> : k_hp_seg_chunk<0>);
-        const auto krun = ch == 8 ? k_hp_run<8> : (ch == 4 ? k_hp_run<4> : k_hp_run<0>);
+        // complete-line stores for the output walk (k_hp_run_lines): throughput layout, planar input, every position that
+        // matters a multiple of 32 steps
+        const bool hp_lines = d->t.line_stores >= 0 && ch == 0 && l.merge && (g.n_w & 31) == 0 && (g.n_wb & 31) == 0 &&
+                              (g.V & 31) == 0 && (g.U & 31) == 0 && (g.Nv & 3) == 0 && (l.hp_L & 31) == 0 &&
+                              ((l.hp_L / l.hp_S) & 31) == 0 && l.hp_L % l.hp_S == 0;
+        const auto krun = hp_lines ? k_hp_run_lines : (ch == 8 ? k_hp_run<8> : (ch == 4 ? k_hp_run<4> : k_hp_run<0>));
         std::memcpy(hc.st.b, d->b, sizeof(hc.st.b));
         std::memcpy(hc.st.a, d->a, sizeof(hc.st.a));
         hc.st.L = l.hp_L;
@@ -3794,6 +4011,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     a.S = l.ar_S;
     {   // walk-through chunks as their own pass 0 (k_ar_warm_both): the merged layout with 16-byte-congruent buffers
         a.through = (d->t.walk_through >= 0 && l.merge && l.ar_sym && (g.U & 3) == 0 && (l.ar_L & 3) == 0) ? 1 : 0;
+        // complete-line stores for the output walks (walk_lines): the throughput layout, everything a multiple of 32 steps
+        a.lines = (d->t.line_stores >= 0 && a.through && (g.U & 31) == 0 && (l.ar_L & 31) == 0) ? 1 : 0;
     }
     // dB and the per-chunk sums of the closed-form guess in one pass whenever both are wanted and the geometry
     // allows 16-byte groups (otherwise k_rect_db, then k_ar_sym_local reading the dB stream once more)
@@ -3832,7 +4051,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         if (l.ar_sym) {
             const int64_t ntg = chains * cdiv(l.ar_chunks, l.ar_S);  // one run per group of S chunks
             if (l.merge)
-                hipLaunchKernelGGL(k_ar_warm_both, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used, used + 2 * nt);
+                hipLaunchKernelGGL(a.lines ? k_ar_warm_both<true> : k_ar_warm_both<false>, dim3((unsigned)cdiv(ntg, 64)), dim3(64), 0,
+                                   stream, a, ntg, used, used + 2 * nt);
             else
                 hipLaunchKernelGGL(k_ar_warm2, dim3(2 * (unsigned)cdiv(ntg, 64)), dim3(64), 0, stream, a, ntg, used);
             OFP_LAUNCH_CHECK("k_ar_warm2");
@@ -3842,10 +4062,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         }
         if (!hv_fm) {
             pend.ar_nv = l.ar_chunks > 1 ? std::max(2, std::min(AHEAD_MAX_PASSES / 2, d->ar_pass_hint)) : 0;
-            if (int rc = run_jacobi_ahead("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, pass_flags, pend.ar_nv, stream))
+            if (int rc = run_jacobi_ahead("follower stage", a.lines ? k_ar_chunk<true> : k_ar_chunk<false>, a, nt, l.ar_chunks, used, pass_flags, pend.ar_nv, stream))
                 return rc;
         } else {
-            int rc = run_jacobi("follower stage", k_ar_chunk, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
+            int rc = run_jacobi("follower stage", a.lines ? k_ar_chunk<true> : k_ar_chunk<false>, a, nt, l.ar_chunks, used, ctr, d->h_flags, d->t.max_passes,
                                 d->t.verify_group > 0 ? (int)d->t.verify_group : 2, stream, &pend.info[1], &pend.info[3]);
             if (rc != OFP_OK) return rc;
         }

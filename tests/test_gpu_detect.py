@@ -87,6 +87,10 @@ def test_interleaved_layout_matches_planar_and_oracle(det, C, kw):
                    dict(hp_dedupe=1, hp_chunk=3072, hp_warm=8192, hp_candidates=4, hp_early=1, interleaved=3),
                    dict(hp_dedupe=1, hp_chunk=1001 * 4, hp_warm=9000, hp_candidate_offset=-1, interleaved=2),
                    dict(lane_merge=1, hp_dedupe=1, walk_through=-1),
+                   dict(lane_merge=1, hp_dedupe=1, line_stores=-1),
+                   # complete-line stores with whole re-runs, early joins and sub-chunk items in the same waves
+                   dict(lane_merge=1, hp_chunk=4096, hp_warm=6000, hp_candidates=2, hp_early=1, ar_chunk=1024, ar_span=4),
+                   dict(lane_merge=1, hp_chunk=8192, hp_warm=-1, hp_candidates=1, ar_chunk=2048, ar_warm=-1),
                    # walk-through chunks as their own pass 0, with spans and chunk lengths that put group ends, the joint
                    # of the two `rel` pieces and the stream's end in every position; no warm-up: the repairs run through them
                    dict(lane_merge=1, ar_chunk=2048, ar_span=4, mm_chunk=2048, mm_span=5, mm_warm=3000),

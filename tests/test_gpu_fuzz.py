@@ -75,6 +75,8 @@ def random_case(rng):
     if rng.random() < 0.3:
         tuning["interleaved"] = int(rng.choice([-1, 2, 3]))  # planar copies throughout / the IIR stage on the interleaved audio too
     if rng.random() < 0.3:
+        tuning["line_stores"] = -1  # lane-private 16-byte stores in the output walks (default in the merged layout: complete lines)
+    if rng.random() < 0.3:
         tuning["walk_through"] = -1  # every chunk through the chunk pass (default: walk-through chunks are their own pass 0)
     return x, kw, tuning
 

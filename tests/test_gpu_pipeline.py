@@ -89,6 +89,8 @@ def test_result_is_independent_of_time_parallel_tuning_and_idempotent(mods):
                    dict(lane_merge=1),         # fast/slow follower and min/max as one lane per chunk
                    dict(lane_merge=1, ar_chunk=2048, ar_warm=9000, mm_chunk=2048, mm_warm=6000, ar_span=4, mm_span=4),
                    dict(lane_merge=1, mm_chunk=1024, mm_warm=-1),   # no tracker warm-up: the repair passes do the work
+                   dict(lane_merge=1, line_stores=-1),   # lane-private stores in the output walks (default here: complete lines)
+                   dict(lane_merge=1, hp_early=1, hp_candidates=2, hp_warm=6000, hp_chunk=4096),   # ... with many breaks
                    dict(lane_merge=1, walk_through=-1),  # every chunk through the chunk pass (default: walk-through chunks are pass 0)
                    dict(lane_merge=1, ar_span=8, mm_span=4, ar_chunk=8192, mm_chunk=8192),
                    dict(lane_merge=1, interleaved=-1),   # planar copies of `rel` and the input throughout
