@@ -168,8 +168,10 @@ typedef struct ofp_detect_tuning {
     int64_t line_stores;         /* throughput layout (lane_merge), everything a multiple of 32 steps: the output walks of
                                     the IIR stage and the followers hand every batch of 32 outputs over through LDS and
                                     the wave stores complete 128-byte lines (8 lanes x 16 B) instead of 64 lane-private
-                                    16-byte pieces per instruction: +11 % frames/s in flight, slower for a lone call.
-                                    0 on, < 0 off.  Results do not change. */
+                                    16-byte pieces per instruction: +11 % frames/s in flight, +5 % for a lone BIG call
+                                    (C3), slower for a small one.  0 auto (the throughput layout, or launches of more
+                                    than two / half a wave per SIMD), 1 whenever the sizes allow, < 0 off.  Results do
+                                    not change. */
 } ofp_detect_tuning;
 
 typedef struct ofp_detector ofp_detector; /* opaque */

@@ -3808,7 +3808,8 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
         const auto kseg_chunk = ch == 8 ? k_hp_seg_chunk<8> : (ch == 4 ? k_hp_seg_chunk<4> : k_hp_seg_chunk<0>);
         // complete-line stores for the output walk (k_hp_run_lines): throughput layout, planar input, every position that
         // matters a multiple of 32 steps
-        const bool hp_lines = d->t.line_stores >= 0 && ch == 0 && l.merge && (g.n_w & 31) == 0 && (g.n_wb & 31) == 0 &&
+        const bool hp_lines = d->t.line_stores >= 0 && ch == 0 &&
+                              (l.merge || d->t.line_stores > 0 || chains * l.hp_chunks * l.hp_S >= (int64_t)2 * 64 * 4 * d->n_cus) &&  // (calls in flight, or a big one) (g.n_w & 31) == 0 && (g.n_wb & 31) == 0 &&
                               (g.V & 31) == 0 && (g.U & 31) == 0 && (g.Nv & 3) == 0 && (l.hp_L & 31) == 0 &&
                               ((l.hp_L / l.hp_S) & 31) == 0 && l.hp_L % l.hp_S == 0;
         const auto krun = hp_lines ? k_hp_run_lines : (ch == 8 ? k_hp_run<8> : (ch == 4 ? k_hp_run<4> : k_hp_run<0>));
@@ -4012,7 +4013,7 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     {   // walk-through chunks as their own pass 0 (k_ar_warm_both): the merged layout with 16-byte-congruent buffers
         a.through = (d->t.walk_through >= 0 && l.merge && l.ar_sym && (g.U & 3) == 0 && (l.ar_L & 3) == 0) ? 1 : 0;
         // complete-line stores for the output walks (walk_lines): the throughput layout, everything a multiple of 32 steps
-        a.lines = (d->t.line_stores >= 0 && a.through && (g.U & 31) == 0 && (l.ar_L & 31) == 0) ? 1 : 0;
+        a.lines = (d->t.line_stores >= 0 && (a.through || d->t.line_stores > 0 || chains * l.ar_chunks >= (int64_t)32 * 4 * d->n_cus) && (g.U & 31) == 0 && (l.ar_L & 31) == 0) ? 1 : 0;
     }
     // dB and the per-chunk sums of the closed-form guess in one pass whenever both are wanted and the geometry
     // allows 16-byte groups (otherwise k_rect_db, then k_ar_sym_local reading the dB stream once more)
