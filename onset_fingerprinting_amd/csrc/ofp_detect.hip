@@ -528,12 +528,12 @@ __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64
 // 16-byte aligned: every shape of the BASELINE configs): 16-byte global accesses on both sides and shifts instead of
 // the two integer divisions per element of the general path -- round 3's instruction counters showed this pure data
 // movement issuing as many vector instructions per step (376 M wave-instructions at 16 clips) as the dB pass.
-__global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
-                                                      int64_t N, int C, int TU, int64_t n_w, int64_t Nv) {
-    extern __shared__ float tile[];  // [C][TU+4]
+__device__ __forceinline__ void transpose_in_tile(const float* __restrict__ x, float* __restrict__ xt, int64_t N, int C, int TU,
+                                                  int64_t n_w, int64_t Nv, int64_t tile_x, float* tile) {
+    // tile: [C][TU+4]
     const int S = TU + 4;
     const int64_t clip = blockIdx.y;
-    const int64_t t0 = (int64_t)blockIdx.x * TU;
+    const int64_t t0 = tile_x * TU;
     const int nt = (int)min<int64_t>(TU, N - t0);
     const float* src = x + (clip * N + t0) * C;
     const int total = nt * C;
@@ -574,6 +574,16 @@ __global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ 
         const float v = tile[c * S + t];
         row[n_w + t0 + t] = v;
         if (t0 + t < n_w) row[t0 + t] = v;  // the warm-up part of the stream (detection.py:70)
+    }
+}
+
+// (several tiles per workgroup: see k_rel_out)
+__global__ __launch_bounds__(256) void k_transpose_in(const float* __restrict__ x, float* __restrict__ xt,
+                                                      int64_t N, int C, int TU, int64_t n_w, int64_t Nv, int64_t n_tiles) {
+    extern __shared__ float tile[];
+    for (int64_t tx = blockIdx.x; tx < n_tiles; tx += gridDim.x) {
+        transpose_in_tile(x, xt, N, C, TU, n_w, Nv, tx, tile);
+        __syncthreads();
     }
 }
 
@@ -2221,17 +2231,17 @@ __global__ __launch_bounds__(64) void k_rect_db_sym(ArArgs a, float* __restrict_
 // "none yet"): k_block_scan then reads a block's samples only if they can matter (see there).  Values are
 // non-negative (clipped, :754), so their bit patterns order like the values; NaN is ignored on both sides, as a
 // comparison with a threshold ignores it.
-__global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
-                                                 float floor_db, int TU, uint32_t* __restrict__ sum_max,
-                                                 uint32_t* __restrict__ sum_minv, int64_t nb, float* __restrict__ rel_warm,
-                                                 int planar) {
+__device__ __forceinline__ void rel_out_tile(const Geom& g, float* __restrict__ buf, float* __restrict__ rel_out,
+                                             float floor_db, int TU, uint32_t* __restrict__ sum_max,
+                                             uint32_t* __restrict__ sum_minv, int64_t nb, float* __restrict__ rel_warm,
+                                             int planar, int64_t tile_x, float* tile) {
     // rel_warm: the rows of the warm-up part in the output's interleaved order ([clip][n_wb][C]), for the tracker's
     // *_il kernels; planar = 0: the planar series are not written back (nothing reads them then)
-    extern __shared__ float tile[];  // [C][TU+4], then the tile's summaries [2][C][nbt]
+    // tile: [C][TU+4], then the tile's summaries [2][C][nbt]
     const int C = g.C;
     const int S = TU + 4;
     const int64_t clip = blockIdx.y;
-    const int64_t u0 = (int64_t)blockIdx.x * TU;
+    const int64_t u0 = tile_x * TU;
     const int nt = (int)min<int64_t>(TU, g.U - u0);
     const int total = nt * C;
     // main blocks this tile touches: j0 .. j0 + nbt - 1 (host: summaries only with B a multiple of 4 and >= 32)
@@ -2334,6 +2344,20 @@ __global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf
         const int64_t m = u0 + t - g.n_wb;
         if (m >= 0) dst[m * C + c] = tile[c * S + t];
         else if (dstw) dstw[(u0 + t) * C + c] = tile[c * S + t];
+    }
+}
+
+// (a workgroup takes several tiles in turn: one workgroup per 2 048 values made the launch 540 000 workgroups for 48 C2
+//  clips, and in flight -- where it competes with seven other kernels for every dispatch -- it took 7.5 x its lone time,
+//  against 2 x for the dB pass with its 34 000 workgroups)
+__global__ __launch_bounds__(256) void k_rel_out(Geom g, float* __restrict__ buf, float* __restrict__ rel_out,
+                                                 float floor_db, int TU, uint32_t* __restrict__ sum_max,
+                                                 uint32_t* __restrict__ sum_minv, int64_t nb, float* __restrict__ rel_warm,
+                                                 int planar, int64_t n_tiles) {
+    extern __shared__ float tile[];
+    for (int64_t tx = blockIdx.x; tx < n_tiles; tx += gridDim.x) {
+        rel_out_tile(g, buf, rel_out, floor_db, TU, sum_max, sum_minv, nb, rel_warm, planar, tx, tile);
+        __syncthreads();  // (the tile and its summaries are free again)
     }
 }
 
@@ -3775,8 +3799,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
             OFP_LAUNCH_CHECK("k_zero");
         }
         if (!l.in_il) {
-            hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)cdiv(N, l.tu), (unsigned)n_clips), dim3(256), tile_lds,
-                               stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv);
+            const int64_t n_tiles = cdiv(N, l.tu);
+            const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, std::max<int64_t>(1, (int64_t)32 * d->n_cus / n_clips));
+            hipLaunchKernelGGL(k_transpose_in, dim3(gx, (unsigned)n_clips), dim3(256), tile_lds,
+                               stream, d_x, xt, N, g.C, l.tu, g.n_w, g.Nv, n_tiles);
             OFP_LAUNCH_CHECK("k_transpose_in");
         }
         if (timed) OFP_HIP(hipEventRecord(ev[8], stream));
@@ -4080,8 +4106,10 @@ static int detect_impl(ofp_detector* d, const float* d_x, int64_t n_clips, int64
     uint32_t* sum_minv = use_sum ? sum_max + n_clips * l.nb * g.C : nullptr;
     if (from_stage <= 1) {
         const size_t lds = tile_lds + (use_sum ? (size_t)2 * g.C * (l.tu / g.B + 2) * 4 : 0);
-        hipLaunchKernelGGL(k_rel_out, dim3((unsigned)cdiv(g.U, l.tu), (unsigned)n_clips), dim3(256), lds, stream, g, dif, d_rel,
-                           p.floor_db, l.tu, sum_max, sum_minv, l.nb, mm_il ? rel_warm : nullptr, mm_il ? 0 : 1);
+        const int64_t n_tiles = cdiv(g.U, l.tu);
+        const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, std::max<int64_t>(1, (int64_t)32 * d->n_cus / n_clips));
+        hipLaunchKernelGGL(k_rel_out, dim3(gx, (unsigned)n_clips), dim3(256), lds, stream, g, dif, d_rel,
+                           p.floor_db, l.tu, sum_max, sum_minv, l.nb, mm_il ? rel_warm : nullptr, mm_il ? 0 : 1, n_tiles);
         OFP_LAUNCH_CHECK("k_rel_out");
     }
     if (timed) OFP_HIP(hipEventRecord(ev[4], stream));
