@@ -17,7 +17,7 @@ Workloads (BASELINE.json configs):
   c2  (default at N = 1)  `--clips` (default 48) DISTINCT 8-channel 60 s clips per GPU and step
       (configs[1], the configuration the metric is quoted on, as a batch: one library call processes
       the clips side by side -- 384 chains, 4.4 GB of audio; rounds 1-2 used 16: the larger batch lets the
-      detector's speculative passes use longer chunks, 145 -> 173 M frames/s with the same command).
+      detector's speculative passes use longer chunks, 145 -> 173 M frames/s with the same command; 212 M on the last build of round 3).
       Every rank owns its own clips: scaling "weak".
       `config.one_clip_per_step` is the same path on ONE clip per step (8 chains, latency-bound).
   c4  (default at N > 1)  512 clips x 4 ch x 10 s in total, sharded contiguously over the ranks
@@ -383,7 +383,7 @@ def main():
     else:
         D = 6
     # Steps per call (strong scaling, small shards): a rank's 64 clips are a small call -- twelve of them in flight reach
-    # 115 M frames/s where 512 clips per call reach 155-160 M.  The steps are independent and their batches
+    # 123 M frames/s where 512 clips per call reach 184 M.  The steps are independent and their batches
     # are resident before the timed region, so G consecutive steps' batches go through ONE call (G x n_local clips side
     # by side, ~512-640 clips); each step's records are then packed and exchanged on their own, in step order.  G divides
     # K so that the timed region is whole calls.
